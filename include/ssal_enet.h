@@ -1,0 +1,141 @@
+/*
+ * ssal_enet.h -- C ABI of libssal_hip.so: the MI355X (gfx950) pool-scoring hot path.
+ *
+ * The reference (alfrunesiq/SemanticSegmentationActiveLearning) has no FFI: the path sits behind a
+ * Python object API (models.ENet, xops.*, and score tensors assembled inline in active_learning.py)
+ * executed by the TensorFlow runtime.  Each entry point below states the reference interface it
+ * replaces (file:line, relative to the reference root).  INTEGRATION.md shows the ctypes stub a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / HIP types (a stream is passed as void* = hipStream_t).
+ *   - every function returns an int status (SSAL_OK == 0); nothing throws across the boundary.
+ *     ssal_last_error() returns a thread-local message for the last non-zero status.
+ *   - "dev" pointers are device (HBM) pointers owned by the caller and only borrowed for the call;
+ *     "host" pointers are host memory.  The library owns only the weights inside a handle.
+ *   - activations are fp32 NHWC, conv kernels HWIO, transposed-conv kernels HW-O-I (TF layouts);
+ *     all launches are stream-ordered and asynchronous; a handle is re-entrant per stream as long
+ *     as each concurrent call gets its own workspace.
+ */
+#ifndef SSAL_ENET_H
+#define SSAL_ENET_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSAL_OK        0
+#define SSAL_EINVAL    1 /* bad argument (maps to ValueError) */
+#define SSAL_EHIP      2 /* HIP runtime error */
+#define SSAL_ENOTIMPL  3 /* maps to NotImplementedError (active_learning.py:259-260) */
+#define SSAL_ESTATE    4 /* handle not committed / tensor missing */
+#define SSAL_ENOMEM    5 /* workspace too small */
+
+/* acquisition measures, active_learning.py:239-260 (conf/default_params.json "measure") */
+#define SSAL_MEASURE_ENTROPY     0
+#define SSAL_MEASURE_MARGIN      1
+#define SSAL_MEASURE_CONFIDENCE  2
+
+typedef struct ssal_enet ssal_enet;
+
+const char *ssal_version(void);
+const char *ssal_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Model handle: replaces the models.ENet object (models/__init__.py:1-3, models/enet/enet.py:6-407).
+ * Tensor names are the reference attribute names "<Layer>.<attr>", e.g. "Initial.kernel",
+ * "Bottleneck2_3.conv_kernel.0" (KernelCol, [5,1,f,f]) / ".1" (KernelRow, [1,5,f,f]),
+ * "Bottleneck4_0.res_kernel", "Final.kernel"  (enet_modules.py:139-187,366-523,730-865,1070-1214,1349-1356).
+ * ---------------------------------------------------------------------------------------------- */
+int ssal_enet_create(int c_in, int classes, ssal_enet **out);
+int ssal_enet_destroy(ssal_enet *net);
+int ssal_enet_num_tensors(const ssal_enet *net);
+int ssal_enet_tensor_info(const ssal_enet *net, int i, const char **name, int *ndim, int64_t dims[4]);
+/* copy one parameter tensor from host memory into the handle (staged until commit) */
+int ssal_enet_set_tensor(ssal_enet *net, const char *name, const float *host, int64_t numel);
+/* fold the batch-norm statistics (extra_ops.py:181-184, eps=1e-3), re-layout kernels and upload */
+int ssal_enet_commit(ssal_enet *net, void *stream);
+/* bytes of device scratch needed by forward/score for a batch of n images of h x w */
+int64_t ssal_enet_workspace_bytes(const ssal_enet *net, int n, int h, int w);
+
+/* ENet.call(inputs, training=False) -> logits   (models/enet/enet.py:320-407)
+ * x_dev: [n,h,w,c_in] fp32, logits_dev: [n,h,w,classes] fp32; h,w divisible by 8. */
+int ssal_enet_forward_nhwc(ssal_enet *net, const float *x_dev, int n, int h, int w,
+                           float *logits_dev, void *ws_dev, int64_t ws_bytes, void *stream);
+
+/* ENet.call + softmax + acquisition measure + float64 per-image mean, fused
+ * (active_learning.py:229-263: pseudo_logits, pseudo_label, pseudo_prob, pseudo_confidence,
+ *  pseudo_mean_confidence, pseudo_mask).  The logits never reach HBM.
+ * scores_dev: [n] float64 (required).  Optional outputs (NULL to skip):
+ *   label_dev [n,h,w] uint8  = argmax_k logits                      (:234-236)
+ *   mask_dev  [n,h,w] uint8  = conf < threshold ? 0 : 1             (:265-269)
+ *   conf_dev  [n,h,w] fp32   = per-pixel confidence                 (:243-258) */
+int ssal_enet_score_nhwc(ssal_enet *net, const float *x_dev, int n, int h, int w, int measure,
+                         float threshold, double *scores_dev, uint8_t *label_dev, uint8_t *mask_dev,
+                         float *conf_dev, void *ws_dev, int64_t ws_bytes, void *stream);
+
+/* Byte offsets into the workspace of the last forward/score call of the tensors behind
+ * ENet.endpoint_outputs (models/enet/enet.py:311-318): offs[0] bottleneck5_1 [n,h/2,w/2,16],
+ * offs[1] bottleneck4_2 [n,h/4,w/4,64], offs[2] bottleneck3_8 [n,h/8,w/8,128]. */
+int ssal_enet_endpoint_offsets(const ssal_enet *net, int n, int h, int w, int64_t offs[3]);
+
+/* Run ONE layer of the handle (Layer.__call__ of enet_modules.py: Initial :190-224, Bottleneck
+ * :526-599, BottleneckDownsample :868-938, BottleneckUpsample :1217-1292, Final :1359-1381).
+ * x_dev [n,h,w,cin] -> y_dev (shape by layer kind).  argmax tensors use the reference's int64
+ * per-image index (y*W + x)*C + c: argmax_out_dev is written by a Downsample
+ * layer, argmax_in_dev is consumed by an Upsample layer; NULL otherwise. */
+int ssal_enet_run_layer(ssal_enet *net, const char *layer, const float *x_dev, int n, int h, int w,
+                        float *y_dev, int64_t *argmax_out_dev, const int64_t *argmax_in_dev,
+                        void *ws_dev, int64_t ws_bytes, void *stream);
+int64_t ssal_enet_layer_workspace_bytes(const ssal_enet *net, const char *layer, int n, int h, int w);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stand-alone operators
+ * ---------------------------------------------------------------------------------------------- */
+
+/* softmax + measure + float64 mean on materialised logits (active_learning.py:239-263) */
+int64_t ssal_score_workspace_bytes(int n, int h, int w);
+int ssal_score_logits_nhwc(const float *logits_dev, int n, int h, int w, int classes, int measure,
+                           float threshold, double *scores_dev, uint8_t *label_dev,
+                           uint8_t *mask_dev, float *conf_dev, void *ws_dev, int64_t ws_bytes,
+                           void *stream);
+
+/* tf.nn.max_pool_with_argmax(ksize 2x2, strides 2, SAME, Targmax=int64) (enet_modules.py:927-929);
+ * include_batch selects the TF<=1.13 CPU index convention (extra_ops.py:63-81). */
+int ssal_max_pool_with_argmax_2x2(const float *x_dev, int n, int h, int w, int c, float *y_dev,
+                                  int64_t *argmax_dev, int include_batch, void *stream);
+/* xops.unpool_2d(inputs, idx, strides=[1,2,2,1])  (models/util/extra_ops.py:28-86) */
+int ssal_unpool_2d(const float *x_dev, const int64_t *idx_dev, int n, int h, int w, int c,
+                   int idx_has_batch, float *y_dev, void *stream);
+/* xops.prelu(x, alpha)  (models/util/extra_ops.py:9-26) */
+int ssal_prelu(const float *x_dev, int64_t pixels, int c, const float *alpha_dev, float *y_dev,
+               void *stream);
+/* xops.batch_norm(..., training=False)  (models/util/extra_ops.py:154-185) */
+int ssal_batch_norm_inference(const float *x_dev, int64_t pixels, int c, const float *mean_dev,
+                              const float *var_dev, const float *gamma_dev, const float *beta_dev,
+                              float *y_dev, void *stream);
+/* tf.nn.conv2d(x, kernel HWIO, strides [1,s,s,1], dilations [1,d,d,1], "SAME")
+ * (enet_modules.py:205,538,554,559,565,581,880,895,911,1236,1267,1285) */
+int ssal_conv2d_same(const float *x_dev, int n, int h, int w, int cin, const float *kernel_dev,
+                     int kh, int kw, int cout, int stride, int dilation, float *y_dev, void *stream);
+/* tf.nn.conv2d_transpose(x, kernel [3,3,cout,cin], strides 2, "SAME") -> [n,2h,2w,cout]
+ * (enet_modules.py:1251-1255, 1376-1380) */
+int ssal_conv2d_transpose_3x3_s2(const float *x_dev, int n, int h, int w, int cin,
+                                 const float *kernel_dev, int cout, float *y_dev, void *stream);
+/* tf.image.resize_bilinear(x, [oh,ow]) with TF-1.13 defaults (align_corners=False, legacy
+ * src = dst * in/out mapping)  (inference.py:96-99) */
+int ssal_resize_bilinear(const float *x_dev, int n, int h, int w, int c, int oh, int ow,
+                         float *y_dev, void *stream);
+
+/* Synthetic Cityscapes-shaped frames for benchmarking/tests: frame f of the pool is a
+ * pure function of (seed, f); out_dev [count,h,w,c] fp32 = uint8 pixel * (1/255)
+ * (tensortools/input.py:289-290 convert_image_dtype).  Host twin: synthetic.synth_frames_u8(). */
+int ssal_synth_frames_nhwc(uint64_t seed, int64_t first_frame, int count, int h, int w, int c,
+                           float *out_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSAL_ENET_H */

@@ -1,0 +1,127 @@
+"""ctypes binding of libssal_hip.so (C ABI declared in include/ssal_enet.h).
+
+The HIP library is the product path.  There is NO CPU fallback: if the shared object is missing
+or a call fails, the error is raised loudly.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libssal_hip.so")
+
+SSAL_OK, SSAL_EINVAL, SSAL_EHIP, SSAL_ENOTIMPL, SSAL_ESTATE, SSAL_ENOMEM = range(6)
+
+MEASURES = {"entropy": 0, "margin": 1, "confidence": 2}
+
+_c = ctypes
+_vp, _i, _i64, _f = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float
+
+# symbol -> (restype, argtypes); one row per declaration in include/ssal_enet.h
+PROTOTYPES = {
+    "ssal_version": (_c.c_char_p, []),
+    "ssal_last_error": (_c.c_char_p, []),
+    "ssal_enet_create": (_i, [_i, _i, _c.POINTER(_vp)]),
+    "ssal_enet_destroy": (_i, [_vp]),
+    "ssal_enet_num_tensors": (_i, [_vp]),
+    "ssal_enet_tensor_info": (_i, [_vp, _i, _c.POINTER(_c.c_char_p), _c.POINTER(_i), _c.POINTER(_i64)]),
+    "ssal_enet_set_tensor": (_i, [_vp, _c.c_char_p, _vp, _i64]),
+    "ssal_enet_commit": (_i, [_vp, _vp]),
+    "ssal_enet_workspace_bytes": (_i64, [_vp, _i, _i, _i]),
+    "ssal_enet_forward_nhwc": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i64, _vp]),
+    "ssal_enet_score_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "ssal_enet_endpoint_offsets": (_i, [_vp, _i, _i, _i, _c.POINTER(_i64)]),
+    "ssal_enet_run_layer": (_i, [_vp, _c.c_char_p, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "ssal_enet_layer_workspace_bytes": (_i64, [_vp, _c.c_char_p, _i, _i, _i]),
+    "ssal_score_workspace_bytes": (_i64, [_i, _i, _i]),
+    "ssal_score_logits_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "ssal_max_pool_with_argmax_2x2": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "ssal_unpool_2d": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ssal_prelu": (_i, [_vp, _i64, _i, _vp, _vp, _vp]),
+    "ssal_batch_norm_inference": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ssal_conv2d_same": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ssal_conv2d_transpose_3x3_s2": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "ssal_resize_bilinear": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ssal_synth_frames_nhwc": (_i, [_c.c_uint64, _i64, _i, _i, _i, _i, _vp, _vp]),
+}
+
+_LIB = None
+
+
+def lib():
+    """Load libssal_hip.so (once).  Raises RuntimeError if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libssal_hip.so is missing (%s). Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'`. "
+                "The MI355X HIP path has no CPU fallback." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = handle
+    return _LIB
+
+
+def check(status):
+    """Map a C-ABI status to the exception the reference would raise."""
+    if status == SSAL_OK:
+        return
+    msg = lib().ssal_last_error().decode("utf-8", "replace")
+    if status == SSAL_EINVAL:
+        raise ValueError(msg)
+    if status == SSAL_ENOTIMPL:
+        raise NotImplementedError(msg)
+    if status == SSAL_ENOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError("libssal_hip: status %d: %s" % (status, msg))
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def require_gpu():
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise RuntimeError("no MI355X/HIP device visible: the scoring path runs on the GPU only "
+                           "(there is no CPU fallback)")
+    return torch
+
+
+def dev_ptr(t, dtype=None, name="tensor"):
+    """Device pointer of a contiguous CUDA(HIP) torch tensor, with dtype / residency checks."""
+    torch = _torch()
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise ValueError("%s must be a torch tensor resident on the GPU" % name)
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError("%s must have dtype %s (got %s)" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    torch = _torch()
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def as_device_f32(x, device=None):
+    """numpy / torch input -> contiguous float32 torch tensor on the current GPU."""
+    torch = require_gpu()
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+    if not isinstance(x, torch.Tensor):
+        raise ValueError("expected a numpy array or torch tensor")
+    if x.dtype != torch.float32:
+        x = x.float()
+    if not x.is_cuda:
+        x = x.cuda(device) if device is not None else x.cuda()
+    return x.contiguous()

@@ -1,0 +1,167 @@
+"""Pool scoring and ranking: host-side mirror of the scoring slice of the reference's
+``active_learning.py`` (EPSILON :39-40, score ops :229-269, ``rank_confidence`` :682-715,
+its caller :776-784).
+
+The per-pixel work (ENet forward, softmax, entropy / margin / confidence, float64 mean) runs in the
+HIP kernels behind ``models.ENet.score``; this module keeps the host control flow of the
+reference: scatter batch results by example index into a float32 vector, filter the unlabelled
+examples, ``np.argpartition`` the ``selection_size`` lowest.  The MI355X addition is pool
+sharding: every rank (one process per GPU) scores a strided shard of the pool and ONE RCCL
+all-gather of ``(index, score)`` pairs over xGMI per ranking pass rebuilds the full vector on every
+rank -- the reference itself is single-process.
+"""
+import numpy as np
+
+from . import _lib
+
+# Lowest representable (normal) float32 -- reference active_learning.py:39-40
+EPSILON = np.finfo(np.float32).tiny
+
+MEASURES = tuple(_lib.MEASURES)  # ("entropy", "margin", "confidence")
+
+
+class ScoringConfig:
+    """The JSON keys the scoring path reads (conf/default_params.json:2,32-35,53-59)."""
+
+    def __init__(self, measure="entropy", selection_size=50, threshold=0.95, batch_size=8,
+                 height=None, width=None):
+        if measure not in _lib.MEASURES:
+            raise NotImplementedError("Uncertainty function not implemented.")
+        self.measure = measure
+        self.selection_size = int(selection_size)
+        self.threshold = float(threshold)
+        self.batch_size = int(batch_size)
+        self.height = height
+        self.width = width
+
+    @classmethod
+    def from_params(cls, params):
+        al = params["active_learning"]
+        net_in = params.get("network", {}).get("input", {})
+        return cls(measure=al["measure"], selection_size=al["selection_size"],
+                   threshold=al["threshold"], batch_size=params["batch_size"],
+                   height=net_in.get("height"), width=net_in.get("width"))
+
+
+def score_logits(logits, measure="entropy", threshold=0.0, return_label=False, return_mask=False,
+                 return_confidence=False):
+    """softmax -> {entropy, margin, confidence} -> float64 mean over (H, W) on materialised logits
+    (reference :239-263): ``pseudo_mean_confidence`` [N] float64, plus optionally ``pseudo_label``
+    (uint8 argmax, :234-236), ``pseudo_mask`` (conf < threshold -> 0 else 1, :265-269) and the
+    per-pixel ``pseudo_confidence``.  Raises NotImplementedError for an unknown measure (:259-260)."""
+    if measure not in _lib.MEASURES:
+        raise NotImplementedError("Uncertainty function not implemented.")
+    torch = _lib.require_gpu()
+    x = _lib.as_device_f32(logits)
+    if x.dim() != 4:
+        raise ValueError("logits must be [N,H,W,classes]")
+    n, h, w, k = x.shape
+    L = _lib.lib()
+    with torch.cuda.device(x.device):
+        nbytes = L.ssal_score_workspace_bytes(n, h, w)
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=x.device)
+        scores = torch.empty((n,), dtype=torch.float64, device=x.device)
+        label = torch.empty((n, h, w), dtype=torch.uint8, device=x.device) if return_label else None
+        mask = torch.empty((n, h, w), dtype=torch.uint8, device=x.device) if return_mask else None
+        conf = torch.empty((n, h, w), dtype=torch.float32, device=x.device) if return_confidence else None
+        _lib.check(L.ssal_score_logits_nhwc(
+            _lib.dev_ptr(x), n, h, w, k, _lib.MEASURES[measure], float(threshold),
+            _lib.dev_ptr(scores), _lib.dev_ptr(label), _lib.dev_ptr(mask), _lib.dev_ptr(conf),
+            _lib.dev_ptr(ws), ws.numel(), _lib.stream_ptr()))
+    if return_label or return_mask or return_confidence:
+        return scores, {"label": label, "mask": mask, "confidence": conf}
+    return scores
+
+
+def select_lowest(unlabelled_confidence, selection_size):
+    """``np.argpartition(conf, k)[:k]`` -- the k lowest-confidence positions as an unordered set
+    (reference :707-712).  The reference raises when ``selection_size == len(unlabelled)`` (kth out
+    of bounds, a known defect); here that case returns every position."""
+    conf = np.asarray(unlabelled_confidence)
+    k = int(np.minimum(len(conf), selection_size))
+    if k <= 0:
+        return np.zeros((0,), dtype=np.int64)
+    if k >= len(conf):
+        return np.arange(len(conf), dtype=np.int64)
+    return np.argpartition(conf, k)[:k].astype(np.int64)
+
+
+def shard_positions(num_examples, rank, world_size):
+    """Strided shard of pool positions for one rank; every rank gets the same count after padding
+    with -1 sentinels (2975 = 8*371 + 7 -> 372 per rank)."""
+    per = (num_examples + world_size - 1) // world_size
+    pos = np.arange(rank, num_examples, world_size, dtype=np.int64)
+    pad = np.full((per - len(pos),), -1, dtype=np.int64)
+    return np.concatenate([pos, pad])
+
+
+def all_gather_scores(local_index, local_score, group=None):
+    """ONE all-gather (RCCL over xGMI for GPU tensors, gloo for CPU tensors) of each rank's
+    ``(index int64, score float64)`` shard; returns the concatenation (sentinel index -1 kept)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local_index, local_score
+    world = dist.get_world_size(group)
+    # one collective: pack the index bits next to the score in a float64 pair -> [per, 2]
+    packed = torch.stack([local_index.to(torch.float64), local_score.to(torch.float64)], dim=1).contiguous()
+    gathered = torch.empty((world * packed.shape[0], 2), dtype=torch.float64, device=packed.device)
+    dist.all_gather_into_tensor(gathered, packed, group=group)
+    return gathered[:, 0].to(torch.int64), gathered[:, 1]
+
+
+def rank_confidence(net, batches, num_examples, unlabelled, selection_size, measure="entropy",
+                    group=None):
+    """Mirror of ``rank_confidence()`` (reference :682-715).
+
+    ``batches`` yields ``(images NHWC float32, example_indices)``; on a multi-GPU job each rank
+    passes only its own shard.  Returns ``(low_conf_examples, unlabelled_confidence)``: the ids (into
+    the full example list) of the ``selection_size`` least confident unlabelled examples and the
+    float32 confidence of every unlabelled example (the reference feeds it to a histogram summary,
+    :781-784)."""
+    torch = _lib.require_gpu()
+    idx_chunks, score_chunks = [], []
+    for images, indices in batches:
+        s = net.score(images, measure=measure)  # [n] float64 on device, stream-ordered
+        score_chunks.append(s)
+        idx_chunks.append(torch.as_tensor(np.asarray(indices, dtype=np.int64), device=s.device))
+    if score_chunks:
+        local_score = torch.cat(score_chunks)
+        local_index = torch.cat(idx_chunks)
+    else:
+        dev = torch.device("cuda", torch.cuda.current_device())
+        local_score = torch.zeros((0,), dtype=torch.float64, device=dev)
+        local_index = torch.zeros((0,), dtype=torch.int64, device=dev)
+    local_index, local_score = _pad_to_common_length(local_index, local_score, group)
+    all_index, all_score = all_gather_scores(local_index, local_score, group)
+    return finish_ranking(all_index.cpu().numpy(), all_score.cpu().numpy(), num_examples,
+                          unlabelled, selection_size)
+
+
+def _pad_to_common_length(index, score, group):
+    """all_gather_into_tensor needs equal shard lengths: pad with the (-1, +inf) sentinel."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return index, score
+    n = torch.tensor([index.numel()], dtype=torch.int64, device=index.device)
+    dist.all_reduce(n, op=dist.ReduceOp.MAX, group=group)
+    pad = int(n.item()) - index.numel()
+    if pad > 0:
+        index = torch.cat([index, torch.full((pad,), -1, dtype=torch.int64, device=index.device)])
+        score = torch.cat([score, torch.full((pad,), float("inf"), dtype=torch.float64, device=score.device)])
+    return index, score
+
+
+def finish_ranking(all_index, all_score, num_examples, unlabelled, selection_size):
+    """Host tail of rank_confidence (reference :685,700,705-715): scatter into a float32 vector by
+    example index (the float64 -> float32 rounding happens here, like ``confidence[batch_indices] =
+    batch_confidence``), filter the unlabelled subset, pick the lowest ``selection_size``."""
+    confidence = np.zeros(num_examples, dtype=np.float32)
+    valid = all_index >= 0
+    confidence[all_index[valid]] = all_score[valid]
+    unlabelled = np.asarray(unlabelled, dtype=np.int64)
+    unlabelled_confidence = confidence[unlabelled]
+    example_indices = select_lowest(unlabelled_confidence, selection_size)
+    low_conf_examples = unlabelled[example_indices]
+    return low_conf_examples, unlabelled_confidence

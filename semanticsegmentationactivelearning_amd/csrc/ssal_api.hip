@@ -1,0 +1,937 @@
+// ssal_api.hip -- the C ABI (include/ssal_enet.h): handle management, weight staging, layer
+// sequencing.  Host C++ only; no torch types.  gfx950 (MI355X) only.
+#include "../../include/ssal_enet.h"
+#include "ssal_internal.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace ssal;
+
+#define SSAL_API extern "C" __attribute__((visibility("default")))
+
+// ------------------------------------------------------------------------------------------------
+// error reporting
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return fail(SSAL_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_));      \
+    } while (0)
+
+SSAL_API const char *ssal_version(void) { return "ssal-hip 0.1 (gfx950)"; }
+SSAL_API const char *ssal_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------------
+// ENet topology (models/enet/enet.py:35-247)
+// ------------------------------------------------------------------------------------------------
+enum Kind { K_INITIAL, K_REGULAR, K_DOWN, K_UP, K_FINAL };
+
+struct LayerSpec {
+    const char *name;
+    Kind kind;
+    int cout;   // output channels (0 for Final: = classes)
+    int dil;    // dilation of the 3x3 conv
+    bool asym;  // (5,1) then (1,5) instead of 3x3
+};
+
+static const LayerSpec kSpecs[] = {
+    {"Initial", K_INITIAL, 16, 1, false},
+    {"Bottleneck1_0", K_DOWN, 64, 1, false},
+    {"Bottleneck1_1", K_REGULAR, 64, 1, false},
+    {"Bottleneck1_2", K_REGULAR, 64, 1, false},
+    {"Bottleneck1_3", K_REGULAR, 64, 1, false},
+    {"Bottleneck1_4", K_REGULAR, 64, 1, false},
+    {"Bottleneck2_0", K_DOWN, 128, 1, false},
+    {"Bottleneck2_1", K_REGULAR, 128, 1, false},
+    {"Bottleneck2_2", K_REGULAR, 128, 2, false},
+    {"Bottleneck2_3", K_REGULAR, 128, 1, true},
+    {"Bottleneck2_4", K_REGULAR, 128, 4, false},
+    {"Bottleneck2_5", K_REGULAR, 128, 1, false},
+    {"Bottleneck2_6", K_REGULAR, 128, 8, false},
+    {"Bottleneck2_7", K_REGULAR, 128, 1, true},
+    {"Bottleneck2_8", K_REGULAR, 128, 16, false},
+    {"Bottleneck3_1", K_REGULAR, 128, 1, false},
+    {"Bottleneck3_2", K_REGULAR, 128, 2, false},
+    {"Bottleneck3_3", K_REGULAR, 128, 1, true},
+    {"Bottleneck3_4", K_REGULAR, 128, 4, false},
+    {"Bottleneck3_5", K_REGULAR, 128, 1, false},
+    {"Bottleneck3_6", K_REGULAR, 128, 8, false},
+    {"Bottleneck3_7", K_REGULAR, 128, 1, true},
+    {"Bottleneck3_8", K_REGULAR, 128, 16, false},
+    {"Bottleneck4_0", K_UP, 64, 1, false},
+    {"Bottleneck4_1", K_REGULAR, 64, 1, false},
+    {"Bottleneck4_2", K_REGULAR, 64, 1, false},
+    {"Bottleneck5_0", K_UP, 16, 1, false},
+    {"Bottleneck5_1", K_REGULAR, 16, 1, false},
+    {"Final", K_FINAL, 0, 1, false},
+};
+static const int kNumLayers = (int)(sizeof(kSpecs) / sizeof(kSpecs[0]));
+
+struct HostTensor {
+    std::string name;
+    std::vector<int64_t> dims;
+    std::vector<float> data;
+    bool set = false;
+    int64_t numel() const
+    {
+        int64_t n = 1;
+        for (auto d : dims) n *= d;
+        return n;
+    }
+};
+
+// device-side view of one layer after commit
+struct DevLayer {
+    Kind kind;
+    int cin, cout, dil;
+    bool asym;
+    int f;  // bottleneck width (proj output channels)
+    int cf; // conv output channels (== f except Upsample: f/2)
+    const float *w = nullptr;  // Initial conv kernel / Final re-laid-out kernel
+    const float *scale = nullptr, *shift = nullptr, *alpha = nullptr;  // Initial
+    const float *proj_w = nullptr, *proj_scale = nullptr, *proj_shift = nullptr, *proj_alpha = nullptr;
+    const float *conv_w = nullptr, *conv_w1 = nullptr;  // conv_w1: second (1,5) kernel when asym
+    const float *conv_scale = nullptr, *conv_shift = nullptr, *conv_alpha = nullptr;
+    const float *exp_w = nullptr, *exp_scale = nullptr, *exp_shift = nullptr;
+    const float *res_w = nullptr, *res_alpha = nullptr;
+};
+
+struct ssal_enet {
+    int c_in = 3, classes = 19;
+    std::vector<HostTensor> tensors;
+    std::map<std::string, int> index;
+    std::vector<DevLayer> layers;
+    float *arena = nullptr;
+    size_t arena_floats = 0;
+    bool committed = false;
+};
+
+static void add_tensor(ssal_enet *h, const std::string &name, std::vector<int64_t> dims)
+{
+    HostTensor t;
+    t.name = name;
+    t.dims = std::move(dims);
+    h->index[name] = (int)h->tensors.size();
+    h->tensors.push_back(std::move(t));
+}
+
+static void add_bn(ssal_enet *h, const std::string &p, int c)
+{
+    add_tensor(h, p + "mean", {c});
+    add_tensor(h, p + "variance", {c});
+    add_tensor(h, p + "gamma", {c});
+    add_tensor(h, p + "beta", {c});
+}
+
+// parameter inventory in the reference's add_weight order
+// (enet_modules.py:139-187, 366-523, 730-865, 1070-1214, 1349-1356)
+static void declare_tensors(ssal_enet *h)
+{
+    int c = h->c_in;
+    for (int li = 0; li < kNumLayers; ++li) {
+        const LayerSpec &s = kSpecs[li];
+        const std::string n = std::string(s.name) + ".";
+        switch (s.kind) {
+        case K_INITIAL:
+            add_tensor(h, n + "kernel", {3, 3, c, 16 - c});
+            add_bn(h, n, 16);
+            add_tensor(h, n + "alpha", {16});
+            c = 16;
+            break;
+        case K_REGULAR: {
+            const int f = c / 4;
+            add_tensor(h, n + "proj_kernel", {1, 1, c, f});
+            add_tensor(h, n + "proj_alpha", {f});
+            add_bn(h, n + "proj_", f);
+            if (s.asym) {
+                add_tensor(h, n + "conv_kernel.0", {5, 1, f, f});
+                add_tensor(h, n + "conv_kernel.1", {1, 5, f, f});
+            } else {
+                add_tensor(h, n + "conv_kernel", {3, 3, f, f});
+            }
+            add_tensor(h, n + "conv_alpha", {f});
+            add_bn(h, n + "conv_", f);
+            add_tensor(h, n + "exp_kernel", {1, 1, f, s.cout});
+            add_bn(h, n + "exp_", s.cout);
+            add_tensor(h, n + "residual_alpha", {s.cout});
+            break;
+        }
+        case K_DOWN: {
+            const int f = 2 * (c / 4);  // enet_modules.py:705
+            add_tensor(h, n + "proj_kernel", {2, 2, c, f});
+            add_tensor(h, n + "proj_alpha", {f});
+            add_bn(h, n + "proj_", f);
+            add_tensor(h, n + "conv_kernel", {3, 3, f, f});
+            add_tensor(h, n + "conv_alpha", {f});
+            add_bn(h, n + "conv_", f);
+            add_tensor(h, n + "exp_kernel", {1, 1, f, s.cout});
+            add_bn(h, n + "exp_", s.cout);
+            add_tensor(h, n + "residual_alpha", {s.cout});
+            c = s.cout;
+            break;
+        }
+        case K_UP: {
+            const int pf = c / 4, cf = pf / 2;  // enet_modules.py:1042-1043
+            add_tensor(h, n + "proj_kernel", {1, 1, c, pf});
+            add_tensor(h, n + "proj_alpha", {pf});
+            add_bn(h, n + "proj_", pf);
+            add_tensor(h, n + "conv_kernel", {3, 3, cf, pf});  // HW-O-I (:1046)
+            add_tensor(h, n + "conv_alpha", {cf});
+            add_bn(h, n + "conv_", cf);
+            add_tensor(h, n + "exp_kernel", {1, 1, cf, s.cout});
+            add_bn(h, n + "exp_", s.cout);
+            add_tensor(h, n + "res_kernel", {1, 1, c, s.cout});
+            add_tensor(h, n + "residual_alpha", {s.cout});
+            c = s.cout;
+            break;
+        }
+        case K_FINAL:
+            add_tensor(h, n + "kernel", {3, 3, h->classes, c});  // HW-O-I (:1341)
+            break;
+        }
+    }
+}
+
+SSAL_API int ssal_enet_create(int c_in, int classes, ssal_enet **out)
+{
+    if (!out) return fail(SSAL_EINVAL, "out is NULL");
+    if (!(c_in == 1 || c_in == 3 || c_in == 4))
+        return fail(SSAL_EINVAL, "c_in must be 1, 3 or 4 (got %d)", c_in);
+    if (classes < 2 || classes > 32)
+        return fail(SSAL_EINVAL, "classes must be in [2,32] (got %d)", classes);
+    ssal_enet *h = new ssal_enet();
+    h->c_in = c_in;
+    h->classes = classes;
+    declare_tensors(h);
+    *out = h;
+    return SSAL_OK;
+}
+
+SSAL_API int ssal_enet_destroy(ssal_enet *net)
+{
+    if (!net) return SSAL_OK;
+    if (net->arena) (void)hipFree(net->arena);
+    delete net;
+    return SSAL_OK;
+}
+
+SSAL_API int ssal_enet_num_tensors(const ssal_enet *net) { return net ? (int)net->tensors.size() : 0; }
+
+SSAL_API int ssal_enet_tensor_info(const ssal_enet *net, int i, const char **name, int *ndim,
+                                   int64_t dims[4])
+{
+    if (!net || i < 0 || i >= (int)net->tensors.size()) return fail(SSAL_EINVAL, "bad tensor index %d", i);
+    const HostTensor &t = net->tensors[i];
+    if (name) *name = t.name.c_str();
+    if (ndim) *ndim = (int)t.dims.size();
+    if (dims)
+        for (size_t d = 0; d < 4; ++d) dims[d] = d < t.dims.size() ? t.dims[d] : 1;
+    return SSAL_OK;
+}
+
+SSAL_API int ssal_enet_set_tensor(ssal_enet *net, const char *name, const float *host, int64_t numel)
+{
+    if (!net || !name || !host) return fail(SSAL_EINVAL, "NULL argument");
+    auto it = net->index.find(name);
+    if (it == net->index.end()) return fail(SSAL_EINVAL, "unknown tensor '%s'", name);
+    HostTensor &t = net->tensors[it->second];
+    if (numel != t.numel())
+        return fail(SSAL_EINVAL, "tensor '%s': expected %lld elements, got %lld", name,
+                    (long long)t.numel(), (long long)numel);
+    t.data.assign(host, host + numel);
+    t.set = true;
+    net->committed = false;
+    return SSAL_OK;
+}
+
+// ---- commit: fold BN, re-layout transposed kernels, upload one arena ---------------------------
+namespace {
+struct ArenaBuilder {
+    std::vector<float> host;
+    size_t push(const float *p, size_t n)
+    {
+        size_t off = (host.size() + 63) / 64 * 64;  // 256-B alignment
+        host.resize(off + n);
+        memcpy(host.data() + off, p, n * sizeof(float));
+        return off;
+    }
+    size_t push(const std::vector<float> &v) { return push(v.data(), v.size()); }
+};
+
+const std::vector<float> &T(const ssal_enet *h, const std::string &name)
+{
+    return h->tensors[h->index.at(name)].data;
+}
+
+// tf.nn.fused_batch_norm(is_training=False), eps=1e-3 (extra_ops.py:181-184) folded:
+//   s = gamma / sqrt(var + eps), t = fma(-mean, s, beta)
+void fold_bn(const ssal_enet *h, const std::string &prefix, int c, std::vector<float> &s,
+             std::vector<float> &t)
+{
+    const auto &mean = T(h, prefix + "mean"), &var = T(h, prefix + "variance");
+    const auto &gamma = T(h, prefix + "gamma"), &beta = T(h, prefix + "beta");
+    s.resize(c);
+    t.resize(c);
+    for (int i = 0; i < c; ++i) {
+        const float sg = gamma[i] / sqrtf(var[i] + 1e-3f);
+        s[i] = sg;
+        t[i] = fmaf(-mean[i], sg, beta[i]);
+    }
+}
+
+// [3,3,O,I] (TF conv2d_transpose kernel) -> [3][3][I][O]
+std::vector<float> hwoi_to_hwio(const std::vector<float> &w, int O, int I)
+{
+    std::vector<float> r(w.size());
+    for (int t = 0; t < 9; ++t)
+        for (int o = 0; o < O; ++o)
+            for (int i = 0; i < I; ++i) r[((size_t)t * I + i) * O + o] = w[((size_t)t * O + o) * I + i];
+    return r;
+}
+}  // namespace
+
+SSAL_API int ssal_enet_commit(ssal_enet *net, void *stream)
+{
+    if (!net) return fail(SSAL_EINVAL, "net is NULL");
+    for (const auto &t : net->tensors)
+        if (!t.set) return fail(SSAL_ESTATE, "tensor '%s' has not been set", t.name.c_str());
+
+    ArenaBuilder ab;
+    struct Off { size_t v[20]; };
+    std::vector<Off> offs(kNumLayers);
+    std::vector<DevLayer> layers(kNumLayers);
+    int c = net->c_in;
+    std::vector<float> s, t;
+    for (int li = 0; li < kNumLayers; ++li) {
+        const LayerSpec &sp = kSpecs[li];
+        const std::string n = std::string(sp.name) + ".";
+        DevLayer &L = layers[li];
+        Off &o = offs[li];
+        L.kind = sp.kind;
+        L.cin = c;
+        L.dil = sp.dil;
+        L.asym = sp.asym;
+        L.cout = sp.kind == K_FINAL ? net->classes : sp.cout;
+        switch (sp.kind) {
+        case K_INITIAL:
+            o.v[0] = ab.push(T(net, n + "kernel"));
+            fold_bn(net, n, 16, s, t);
+            o.v[1] = ab.push(s);
+            o.v[2] = ab.push(t);
+            o.v[3] = ab.push(T(net, n + "alpha"));
+            L.f = L.cf = 0;
+            break;
+        case K_REGULAR:
+        case K_DOWN:
+        case K_UP: {
+            const int f = sp.kind == K_DOWN ? 2 * (c / 4) : c / 4;
+            const int cf = sp.kind == K_UP ? f / 2 : f;
+            L.f = f;
+            L.cf = cf;
+            o.v[0] = ab.push(T(net, n + "proj_kernel"));
+            fold_bn(net, n + "proj_", f, s, t);
+            o.v[1] = ab.push(s);
+            o.v[2] = ab.push(t);
+            o.v[3] = ab.push(T(net, n + "proj_alpha"));
+            if (sp.asym) {
+                o.v[4] = ab.push(T(net, n + "conv_kernel.0"));
+                o.v[5] = ab.push(T(net, n + "conv_kernel.1"));
+            } else if (sp.kind == K_UP) {
+                o.v[4] = ab.push(hwoi_to_hwio(T(net, n + "conv_kernel"), cf, f));
+                o.v[5] = 0;
+            } else {
+                o.v[4] = ab.push(T(net, n + "conv_kernel"));
+                o.v[5] = 0;
+            }
+            fold_bn(net, n + "conv_", cf, s, t);
+            o.v[6] = ab.push(s);
+            o.v[7] = ab.push(t);
+            o.v[8] = ab.push(T(net, n + "conv_alpha"));
+            o.v[9] = ab.push(T(net, n + "exp_kernel"));
+            fold_bn(net, n + "exp_", L.cout, s, t);
+            o.v[10] = ab.push(s);
+            o.v[11] = ab.push(t);
+            o.v[12] = sp.kind == K_UP ? ab.push(T(net, n + "res_kernel")) : 0;
+            o.v[13] = ab.push(T(net, n + "residual_alpha"));
+            break;
+        }
+        case K_FINAL:
+            o.v[0] = ab.push(hwoi_to_hwio(T(net, n + "kernel"), net->classes, c));
+            L.f = L.cf = 0;
+            break;
+        }
+        c = L.cout;
+    }
+
+    hipStream_t st = (hipStream_t)stream;
+    if (net->arena && net->arena_floats < ab.host.size()) {
+        HIP_TRY(hipFree(net->arena));
+        net->arena = nullptr;
+    }
+    if (!net->arena) {
+        HIP_TRY(hipMalloc((void **)&net->arena, ab.host.size() * sizeof(float)));
+        net->arena_floats = ab.host.size();
+    }
+    HIP_TRY(hipMemcpyAsync(net->arena, ab.host.data(), ab.host.size() * sizeof(float),
+                           hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));  // the staging vector dies at return
+
+    const float *A = net->arena;
+    for (int li = 0; li < kNumLayers; ++li) {
+        DevLayer &L = layers[li];
+        const Off &o = offs[li];
+        switch (L.kind) {
+        case K_INITIAL:
+            L.w = A + o.v[0]; L.scale = A + o.v[1]; L.shift = A + o.v[2]; L.alpha = A + o.v[3];
+            break;
+        case K_FINAL:
+            L.w = A + o.v[0];
+            break;
+        default:
+            L.proj_w = A + o.v[0]; L.proj_scale = A + o.v[1]; L.proj_shift = A + o.v[2];
+            L.proj_alpha = A + o.v[3];
+            L.conv_w = A + o.v[4]; L.conv_w1 = L.asym ? A + o.v[5] : nullptr;
+            L.conv_scale = A + o.v[6]; L.conv_shift = A + o.v[7]; L.conv_alpha = A + o.v[8];
+            L.exp_w = A + o.v[9]; L.exp_scale = A + o.v[10]; L.exp_shift = A + o.v[11];
+            L.res_w = L.kind == K_UP ? A + o.v[12] : nullptr;
+            L.res_alpha = A + o.v[13];
+            break;
+        }
+    }
+    net->layers = std::move(layers);
+    net->committed = true;
+    return SSAL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace carving
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct Bump {
+    char *base;
+    int64_t cap, off = 0;
+    bool ok = true;
+    Bump(void *b, int64_t c) : base((char *)b), cap(c) {}
+    template <typename Tp> Tp *take(int64_t count)
+    {
+        int64_t o = (off + 255) / 256 * 256;
+        int64_t bytes = count * (int64_t)sizeof(Tp);
+        off = o + bytes;
+        if (base && off > cap) ok = false;
+        return base ? (Tp *)(base + o) : nullptr;
+    }
+};
+
+struct LayerTemps {
+    float *t0, *t1, *t2, *t3;
+};
+
+// temp tensor sizes (floats) for one layer at INPUT dims (n,h,w); general = scatter-based unpool
+void layer_temp_floats(const DevLayer &L, int64_t n, int64_t h, int64_t w, bool general, int64_t sz[4])
+{
+    sz[0] = sz[1] = sz[2] = sz[3] = 0;
+    switch (L.kind) {
+    case K_REGULAR:
+        sz[0] = sz[1] = n * h * w * L.f;
+        if (L.asym) sz[2] = n * h * w * L.f;
+        break;
+    case K_DOWN:
+        sz[0] = sz[1] = n * (h / 2) * (w / 2) * L.f;
+        break;
+    case K_UP:
+        sz[0] = n * h * w * L.f;
+        sz[1] = n * 4 * h * w * L.cf;
+        sz[2] = n * h * w * L.cout;
+        if (general) sz[3] = n * 4 * h * w * L.cout;
+        break;
+    default:
+        break;
+    }
+}
+
+ConvArgs conv_args(const float *x, int N, int H, int W, int Cin, const float *w, int KH, int KW,
+                   int Cout, int stride, int dil, float *y)
+{
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.w = w; a.y = y;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.KH = KH; a.KW = KW; a.stride = stride; a.dil = dil;
+    // TF "SAME": out = ceil(in/stride); pad_total = max((out-1)*stride + (k-1)*dil + 1 - in, 0); before = total/2
+    a.Ho = (H + stride - 1) / stride;
+    a.Wo = (W + stride - 1) / stride;
+    int th = (a.Ho - 1) * stride + (KH - 1) * dil + 1 - H; if (th < 0) th = 0;
+    int tw = (a.Wo - 1) * stride + (KW - 1) * dil + 1 - W; if (tw < 0) tw = 0;
+    a.pad_t = th / 2;
+    a.pad_l = tw / 2;
+    a.res_mode = RES_NONE;
+    return a;
+}
+
+#define HIP_RET(expr)                          \
+    do {                                       \
+        hipError_t e_ = (expr);                \
+        if (e_ != hipSuccess) return e_;       \
+    } while (0)
+
+// Bottleneck.call (enet_modules.py:526-599)
+hipError_t run_regular(const DevLayer &L, const float *x, int n, int h, int w, float *y,
+                       const LayerTemps &T, hipStream_t s)
+{
+    const int C = L.cin, f = L.f;
+    ConvArgs p = conv_args(x, n, h, w, C, L.proj_w, 1, 1, f, 1, 1, T.t0);
+    p.scale = L.proj_scale; p.shift = L.proj_shift; p.alpha = L.proj_alpha;
+    HIP_RET(launch_conv(p, s));
+    const float *mid;
+    if (L.asym) {
+        ConvArgs c0 = conv_args(T.t0, n, h, w, f, L.conv_w, 5, 1, f, 1, 1, T.t2);
+        HIP_RET(launch_conv(c0, s));  // no BN / activation between the two 1-D convs (:553-563)
+        ConvArgs c1 = conv_args(T.t2, n, h, w, f, L.conv_w1, 1, 5, f, 1, 1, T.t1);
+        c1.scale = L.conv_scale; c1.shift = L.conv_shift; c1.alpha = L.conv_alpha;
+        HIP_RET(launch_conv(c1, s));
+        mid = T.t1;
+    } else {
+        ConvArgs c0 = conv_args(T.t0, n, h, w, f, L.conv_w, 3, 3, f, 1, L.dil, T.t1);
+        c0.scale = L.conv_scale; c0.shift = L.conv_shift; c0.alpha = L.conv_alpha;
+        HIP_RET(launch_conv(c0, s));
+        mid = T.t1;
+    }
+    ConvArgs e = conv_args(mid, n, h, w, f, L.exp_w, 1, 1, L.cout, 1, 1, y);
+    e.scale = L.exp_scale; e.shift = L.exp_shift; e.alpha = nullptr;
+    e.res_mode = RES_ADD; e.res = x; e.res_C = C; e.res_alpha = L.res_alpha;
+    return launch_conv(e, s);
+}
+
+// BottleneckDownsample.call (enet_modules.py:868-938); code: [n,h/2,w/2,cin] window codes
+hipError_t run_down(const DevLayer &L, const float *x, int n, int h, int w, float *y, uint8_t *code,
+                    const LayerTemps &T, hipStream_t s)
+{
+    const int C = L.cin, f = L.f;
+    ConvArgs p = conv_args(x, n, h, w, C, L.proj_w, 2, 2, f, 2, 1, T.t0);
+    p.scale = L.proj_scale; p.shift = L.proj_shift; p.alpha = L.proj_alpha;
+    HIP_RET(launch_conv(p, s));
+    ConvArgs c0 = conv_args(T.t0, n, h / 2, w / 2, f, L.conv_w, 3, 3, f, 1, L.dil, T.t1);
+    c0.scale = L.conv_scale; c0.shift = L.conv_shift; c0.alpha = L.conv_alpha;
+    HIP_RET(launch_conv(c0, s));
+    ConvArgs e = conv_args(T.t1, n, h / 2, w / 2, f, L.exp_w, 1, 1, L.cout, 1, 1, y);
+    e.scale = L.exp_scale; e.shift = L.exp_shift;
+    e.res_mode = RES_POOL; e.res = x; e.res_C = C; e.code_out = code; e.res_alpha = L.res_alpha;
+    return launch_conv(e, s);
+}
+
+// BottleneckUpsample.call (enet_modules.py:1217-1292).  Either window codes (fast path) or the
+// reference's int64 argmax tensor (general scatter path) selects the unpooling.
+hipError_t run_up(const DevLayer &L, const float *x, int n, int h, int w, float *y,
+                  const uint8_t *code, const int64_t *argmax, const LayerTemps &T, hipStream_t s)
+{
+    const int C = L.cin, pf = L.f, cf = L.cf;
+    ConvArgs p = conv_args(x, n, h, w, C, L.proj_w, 1, 1, pf, 1, 1, T.t0);
+    p.scale = L.proj_scale; p.shift = L.proj_shift; p.alpha = L.proj_alpha;
+    HIP_RET(launch_conv(p, s));
+    HIP_RET(launch_convT(T.t0, n, h, w, pf, L.conv_w, cf, L.conv_scale, L.conv_shift, L.conv_alpha,
+                         T.t1, s));
+    ConvArgs r = conv_args(x, n, h, w, C, L.res_w, 1, 1, L.cout, 1, 1, T.t2);  // no BN (:1285-1287)
+    HIP_RET(launch_conv(r, s));
+    ConvArgs e = conv_args(T.t1, n, 2 * h, 2 * w, cf, L.exp_w, 1, 1, L.cout, 1, 1, y);
+    e.scale = L.exp_scale; e.shift = L.exp_shift; e.res_alpha = L.res_alpha; e.res_C = L.cout;
+    if (code) {
+        e.res_mode = RES_UNPOOL; e.res = T.t2; e.code_in = code;
+    } else {
+        HIP_RET(launch_unpool_scatter(T.t2, argmax, n, h, w, L.cout, 0, T.t3, s));
+        e.res_mode = RES_ADD; e.res = T.t3;
+    }
+    return launch_conv(e, s);
+}
+
+struct NetWorkspace {
+    float *a0, *a1;        // [n,h/2,w/2,16]
+    float *s1a, *s1b;      // [n,h/4,w/4,64]
+    float *s2a, *s2b;      // [n,h/8,w/8,128]
+    LayerTemps T;
+    uint8_t *code1, *code2;
+    double *partial;
+    int64_t bytes;
+    bool ok;
+};
+
+NetWorkspace carve(const ssal_enet *net, void *ws, int64_t ws_bytes, int64_t n, int64_t h, int64_t w)
+{
+    Bump b(ws, ws_bytes);
+    NetWorkspace W;
+    W.a0 = b.take<float>(n * (h / 2) * (w / 2) * 16);
+    W.a1 = b.take<float>(n * (h / 2) * (w / 2) * 16);
+    W.s1a = b.take<float>(n * (h / 4) * (w / 4) * 64);
+    W.s1b = b.take<float>(n * (h / 4) * (w / 4) * 64);
+    W.s2a = b.take<float>(n * (h / 8) * (w / 8) * 128);
+    W.s2b = b.take<float>(n * (h / 8) * (w / 8) * 128);
+    int64_t mx[4] = {0, 0, 0, 0};
+    int64_t lh = h, lw = w;
+    for (int li = 0; li < kNumLayers; ++li) {
+        const DevLayer &L = net->layers[li];
+        int64_t sz[4];
+        layer_temp_floats(L, n, lh, lw, false, sz);
+        for (int k = 0; k < 4; ++k) mx[k] = sz[k] > mx[k] ? sz[k] : mx[k];
+        if (L.kind == K_INITIAL || L.kind == K_DOWN) { lh /= 2; lw /= 2; }
+        else if (L.kind == K_UP) { lh *= 2; lw *= 2; }
+    }
+    W.T.t0 = b.take<float>(mx[0]);
+    W.T.t1 = b.take<float>(mx[1]);
+    W.T.t2 = b.take<float>(mx[2]);
+    W.T.t3 = nullptr;
+    W.code1 = b.take<uint8_t>(n * (h / 4) * (w / 4) * 16);
+    W.code2 = b.take<uint8_t>(n * (h / 8) * (w / 8) * 64);
+    W.partial = b.take<double>(n * (int64_t)final_score_blocks((int)(h / 2), (int)(w / 2)));
+    W.bytes = b.off;
+    W.ok = b.ok;
+    return W;
+}
+
+int check_dims(const ssal_enet *net, int n, int h, int w)
+{
+    if (!net) return fail(SSAL_EINVAL, "net is NULL");
+    if (!net->committed) return fail(SSAL_ESTATE, "ssal_enet_commit() has not been called");
+    if (n <= 0 || h <= 0 || w <= 0) return fail(SSAL_EINVAL, "bad dims n=%d h=%d w=%d", n, h, w);
+    if (h % 8 || w % 8)
+        return fail(SSAL_EINVAL, "ENet needs H and W divisible by 8 (got %dx%d)", h, w);
+    if ((int64_t)n * h * w > ((int64_t)1 << 34))
+        return fail(SSAL_EINVAL, "batch too large (n=%d h=%d w=%d): split it", n, h, w);
+    return SSAL_OK;
+}
+
+// runs Initial .. Bottleneck5_1; returns the 16-channel half-resolution tensor feeding Final
+hipError_t run_trunk(const ssal_enet *net, const float *x, int n, int h, int w, NetWorkspace &W,
+                     const float **trunk_out, hipStream_t s)
+{
+    const std::vector<DevLayer> &L = net->layers;
+    HIP_RET(launch_initial(x, n, h, w, net->c_in, L[0].w, L[0].scale, L[0].shift, L[0].alpha, W.a0, s));
+    int li = 1;
+    // stage 1
+    HIP_RET(run_down(L[li++], W.a0, n, h / 2, w / 2, W.s1a, W.code1, W.T, s));
+    float *cur = W.s1a, *oth = W.s1b;
+    for (int k = 0; k < 4; ++k) {
+        HIP_RET(run_regular(L[li++], cur, n, h / 4, w / 4, oth, W.T, s));
+        float *t = cur; cur = oth; oth = t;
+    }
+    // stage 2 + 3
+    HIP_RET(run_down(L[li++], cur, n, h / 4, w / 4, W.s2a, W.code2, W.T, s));
+    float *c2 = W.s2a, *o2 = W.s2b;
+    for (int k = 0; k < 16; ++k) {
+        HIP_RET(run_regular(L[li++], c2, n, h / 8, w / 8, o2, W.T, s));
+        float *t = c2; c2 = o2; o2 = t;
+    }
+    // stage 4 (stage-1 buffers are free again)
+    HIP_RET(run_up(L[li++], c2, n, h / 8, w / 8, W.s1a, W.code2, nullptr, W.T, s));
+    cur = W.s1a; oth = W.s1b;
+    for (int k = 0; k < 2; ++k) {
+        HIP_RET(run_regular(L[li++], cur, n, h / 4, w / 4, oth, W.T, s));
+        float *t = cur; cur = oth; oth = t;
+    }
+    // stage 5
+    HIP_RET(run_up(L[li++], cur, n, h / 4, w / 4, W.a0, W.code1, nullptr, W.T, s));
+    HIP_RET(run_regular(L[li++], W.a0, n, h / 2, w / 2, W.a1, W.T, s));
+    *trunk_out = W.a1;
+    return hipSuccess;
+}
+}  // namespace
+
+SSAL_API int64_t ssal_enet_workspace_bytes(const ssal_enet *net, int n, int h, int w)
+{
+    if (!net || !net->committed || n <= 0 || h <= 0 || w <= 0) return -1;
+    NetWorkspace W = carve(net, nullptr, 0, n, h, w);
+    return W.bytes + 256;
+}
+
+SSAL_API int ssal_enet_forward_nhwc(ssal_enet *net, const float *x_dev, int n, int h, int w,
+                                    float *logits_dev, void *ws_dev, int64_t ws_bytes, void *stream)
+{
+    int rc = check_dims(net, n, h, w);
+    if (rc) return rc;
+    if (!x_dev || !logits_dev || !ws_dev) return fail(SSAL_EINVAL, "NULL device pointer");
+    NetWorkspace W = carve(net, ws_dev, ws_bytes, n, h, w);
+    if (!W.ok) return fail(SSAL_ENOMEM, "workspace too small: need %lld bytes, got %lld",
+                           (long long)W.bytes, (long long)ws_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const float *trunk = nullptr;
+    HIP_TRY(run_trunk(net, x_dev, n, h, w, W, &trunk, s));
+    // logits only: the score outputs of the fused kernel go to the scratch partial buffer
+    HIP_TRY(launch_final_score(trunk, n, h / 2, w / 2, net->layers[kNumLayers - 1].w, net->classes,
+                               logits_dev, SSAL_MEASURE_CONFIDENCE, 0.0f, W.partial, nullptr,
+                               nullptr, nullptr, s));
+    return SSAL_OK;
+}
+
+SSAL_API int ssal_enet_score_nhwc(ssal_enet *net, const float *x_dev, int n, int h, int w,
+                                  int measure, float threshold, double *scores_dev,
+                                  uint8_t *label_dev, uint8_t *mask_dev, float *conf_dev,
+                                  void *ws_dev, int64_t ws_bytes, void *stream)
+{
+    int rc = check_dims(net, n, h, w);
+    if (rc) return rc;
+    if (measure < 0 || measure > 2)
+        return fail(SSAL_ENOTIMPL, "Uncertainty function not implemented (measure=%d)", measure);
+    if (!x_dev || !scores_dev || !ws_dev) return fail(SSAL_EINVAL, "NULL device pointer");
+    NetWorkspace W = carve(net, ws_dev, ws_bytes, n, h, w);
+    if (!W.ok) return fail(SSAL_ENOMEM, "workspace too small: need %lld bytes, got %lld",
+                           (long long)W.bytes, (long long)ws_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const float *trunk = nullptr;
+    HIP_TRY(run_trunk(net, x_dev, n, h, w, W, &trunk, s));
+    HIP_TRY(launch_final_score(trunk, n, h / 2, w / 2, net->layers[kNumLayers - 1].w, net->classes,
+                               nullptr, measure, threshold, W.partial, label_dev, mask_dev,
+                               conf_dev, s));
+    HIP_TRY(launch_reduce_mean(W.partial, n, final_score_blocks(h / 2, w / 2), (double)h * (double)w,
+                               scores_dev, s));
+    return SSAL_OK;
+}
+
+// byte offsets (into the workspace passed to forward/score) of the tensors behind
+// ENet.endpoint_outputs (enet.py:311-318): [0] bottleneck5_1 [n,h/2,w/2,16],
+// [1] bottleneck4_2 [n,h/4,w/4,64], [2] bottleneck3_8 [n,h/8,w/8,128]; valid until the next call.
+SSAL_API int ssal_enet_endpoint_offsets(const ssal_enet *net, int n, int h, int w, int64_t offs[3])
+{
+    if (!net || !offs) return fail(SSAL_EINVAL, "NULL argument");
+    if (!net->committed) return fail(SSAL_ESTATE, "ssal_enet_commit() has not been called");
+    NetWorkspace W = carve(net, (void *)256, ((int64_t)1 << 62), n, h, w);
+    const char *base = (const char *)256;
+    offs[0] = (const char *)W.a1 - base;
+    offs[1] = (const char *)W.s1a - base;  // 4_0 -> s1a, 4_1 -> s1b, 4_2 -> s1a
+    offs[2] = (const char *)W.s2a - base;  // 2_0 -> s2a, then 16 ping-pong steps end in s2a
+    return SSAL_OK;
+}
+
+// ---- single layer -------------------------------------------------------------------------------
+static int find_layer(const ssal_enet *net, const char *layer)
+{
+    for (int li = 0; li < kNumLayers; ++li)
+        if (!strcmp(kSpecs[li].name, layer)) return li;
+    (void)net;
+    return -1;
+}
+
+SSAL_API int64_t ssal_enet_layer_workspace_bytes(const ssal_enet *net, const char *layer, int n,
+                                                 int h, int w)
+{
+    if (!net || !net->committed || !layer) return -1;
+    int li = find_layer(net, layer);
+    if (li < 0) return -1;
+    const DevLayer &L = net->layers[li];
+    int64_t sz[4];
+    layer_temp_floats(L, n, h, w, true, sz);
+    int64_t bytes = 1024;
+    for (int k = 0; k < 4; ++k) bytes += sz[k] * 4 + 256;
+    if (L.kind == K_DOWN) bytes += (int64_t)n * (h / 2) * (w / 2) * L.cin + 256;
+    if (L.kind == K_FINAL) bytes += (int64_t)n * final_score_blocks(h, w) * 8 + 256;
+    return bytes;
+}
+
+SSAL_API int ssal_enet_run_layer(ssal_enet *net, const char *layer, const float *x_dev, int n, int h,
+                                 int w, float *y_dev, int64_t *argmax_out_dev,
+                                 const int64_t *argmax_in_dev, void *ws_dev, int64_t ws_bytes,
+                                 void *stream)
+{
+    if (!net || !layer) return fail(SSAL_EINVAL, "NULL argument");
+    if (!net->committed) return fail(SSAL_ESTATE, "ssal_enet_commit() has not been called");
+    if (!x_dev || !y_dev) return fail(SSAL_EINVAL, "NULL device pointer");
+    if (n <= 0 || h <= 0 || w <= 0) return fail(SSAL_EINVAL, "bad dims n=%d h=%d w=%d", n, h, w);
+    int li = find_layer(net, layer);
+    if (li < 0) return fail(SSAL_EINVAL, "unknown layer '%s'", layer);
+    const DevLayer &L = net->layers[li];
+    if ((L.kind == K_INITIAL || L.kind == K_DOWN) && (h % 2 || w % 2))
+        return fail(SSAL_EINVAL, "layer '%s' needs even H and W (got %dx%d)", layer, h, w);
+    const int64_t need = ssal_enet_layer_workspace_bytes(net, layer, n, h, w);
+    if (need > 1024 && (!ws_dev || ws_bytes < need))
+        return fail(SSAL_ENOMEM, "workspace too small: need %lld bytes, got %lld", (long long)need,
+                    (long long)ws_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    Bump b(ws_dev, ws_bytes);
+    int64_t sz[4];
+    layer_temp_floats(L, n, h, w, true, sz);
+    LayerTemps T;
+    T.t0 = b.take<float>(sz[0]);
+    T.t1 = b.take<float>(sz[1]);
+    T.t2 = b.take<float>(sz[2]);
+    T.t3 = b.take<float>(sz[3]);
+    switch (L.kind) {
+    case K_INITIAL:
+        HIP_TRY(launch_initial(x_dev, n, h, w, net->c_in, L.w, L.scale, L.shift, L.alpha, y_dev, s));
+        break;
+    case K_REGULAR:
+        HIP_TRY(run_regular(L, x_dev, n, h, w, y_dev, T, s));
+        break;
+    case K_DOWN: {
+        uint8_t *code = b.take<uint8_t>((int64_t)n * (h / 2) * (w / 2) * L.cin);
+        HIP_TRY(run_down(L, x_dev, n, h, w, y_dev, code, T, s));
+        if (argmax_out_dev)
+            HIP_TRY(launch_codes_to_argmax(code, n, h / 2, w / 2, L.cin, argmax_out_dev, s));
+        break;
+    }
+    case K_UP:
+        if (!argmax_in_dev) return fail(SSAL_EINVAL, "layer '%s' needs argmax_in_dev", layer);
+        HIP_TRY(run_up(L, x_dev, n, h, w, y_dev, nullptr, argmax_in_dev, T, s));
+        break;
+    case K_FINAL: {
+        double *partial = b.take<double>((int64_t)n * final_score_blocks(h, w));
+        HIP_TRY(launch_final_score(x_dev, n, h, w, L.w, net->classes, y_dev,
+                                   SSAL_MEASURE_CONFIDENCE, 0.0f, partial, nullptr, nullptr,
+                                   nullptr, s));
+        break;
+    }
+    }
+    return SSAL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone operators
+// ------------------------------------------------------------------------------------------------
+SSAL_API int64_t ssal_score_workspace_bytes(int n, int h, int w)
+{
+    if (n <= 0 || h <= 0 || w <= 0) return -1;
+    return (int64_t)n * score_blocks(h, w) * 8 + 256;
+}
+
+SSAL_API int ssal_score_logits_nhwc(const float *logits_dev, int n, int h, int w, int classes,
+                                    int measure, float threshold, double *scores_dev,
+                                    uint8_t *label_dev, uint8_t *mask_dev, float *conf_dev,
+                                    void *ws_dev, int64_t ws_bytes, void *stream)
+{
+    if (measure < 0 || measure > 2)
+        return fail(SSAL_ENOTIMPL, "Uncertainty function not implemented (measure=%d)", measure);
+    if (n <= 0 || h <= 0 || w <= 0) return fail(SSAL_EINVAL, "bad dims n=%d h=%d w=%d", n, h, w);
+    if (classes < 2 || classes > 32) return fail(SSAL_EINVAL, "classes must be in [2,32] (got %d)", classes);
+    if (!logits_dev || !scores_dev || !ws_dev) return fail(SSAL_EINVAL, "NULL device pointer");
+    if (ws_bytes < ssal_score_workspace_bytes(n, h, w))
+        return fail(SSAL_ENOMEM, "workspace too small: need %lld bytes, got %lld",
+                    (long long)ssal_score_workspace_bytes(n, h, w), (long long)ws_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    Bump b(ws_dev, ws_bytes);
+    double *partial = b.take<double>((int64_t)n * score_blocks(h, w));
+    HIP_TRY(launch_score_logits(logits_dev, n, h, w, classes, measure, threshold, partial, label_dev,
+                                mask_dev, conf_dev, s));
+    HIP_TRY(launch_reduce_mean(partial, n, score_blocks(h, w), (double)h * (double)w, scores_dev, s));
+    return SSAL_OK;
+}
+
+SSAL_API int ssal_max_pool_with_argmax_2x2(const float *x_dev, int n, int h, int w, int c,
+                                           float *y_dev, int64_t *argmax_dev, int include_batch,
+                                           void *stream)
+{
+    if (!x_dev || !y_dev) return fail(SSAL_EINVAL, "NULL device pointer");
+    if (n <= 0 || h <= 0 || w <= 0 || c <= 0 || h % 2 || w % 2)
+        return fail(SSAL_EINVAL, "bad dims n=%d h=%d w=%d c=%d (H, W must be even)", n, h, w, c);
+    HIP_TRY(launch_maxpool_argmax(x_dev, n, h, w, c, y_dev, argmax_dev, include_batch, (hipStream_t)stream));
+    return SSAL_OK;
+}
+
+SSAL_API int ssal_unpool_2d(const float *x_dev, const int64_t *idx_dev, int n, int h, int w, int c,
+                            int idx_has_batch, float *y_dev, void *stream)
+{
+    if (!x_dev || !idx_dev || !y_dev) return fail(SSAL_EINVAL, "NULL device pointer");
+    if (n <= 0 || h <= 0 || w <= 0 || c <= 0) return fail(SSAL_EINVAL, "bad dims");
+    HIP_TRY(launch_unpool_scatter(x_dev, idx_dev, n, h, w, c, idx_has_batch, y_dev, (hipStream_t)stream));
+    return SSAL_OK;
+}
+
+SSAL_API int ssal_prelu(const float *x_dev, int64_t pixels, int c, const float *alpha_dev,
+                        float *y_dev, void *stream)
+{
+    if (!x_dev || !alpha_dev || !y_dev) return fail(SSAL_EINVAL, "NULL device pointer");
+    if (pixels <= 0 || c <= 0) return fail(SSAL_EINVAL, "bad dims");
+    HIP_TRY(launch_prelu(x_dev, pixels, c, alpha_dev, y_dev, (hipStream_t)stream));
+    return SSAL_OK;
+}
+
+SSAL_API int ssal_batch_norm_inference(const float *x_dev, int64_t pixels, int c,
+                                       const float *mean_dev, const float *var_dev,
+                                       const float *gamma_dev, const float *beta_dev, float *y_dev,
+                                       void *stream)
+{
+    if (!x_dev || !mean_dev || !var_dev || !gamma_dev || !beta_dev || !y_dev)
+        return fail(SSAL_EINVAL, "NULL device pointer");
+    if (pixels <= 0 || c <= 0) return fail(SSAL_EINVAL, "bad dims");
+    hipStream_t s = (hipStream_t)stream;
+    float *fold = nullptr;
+    HIP_TRY(hipMallocAsync((void **)&fold, sizeof(float) * 2 * c, s));
+    hipError_t e = launch_bn_fold(mean_dev, var_dev, gamma_dev, beta_dev, c, fold, fold + c, s);
+    if (e == hipSuccess) e = launch_affine(x_dev, pixels, c, fold, fold + c, y_dev, s);
+    hipError_t e2 = hipFreeAsync(fold, s);
+    if (e != hipSuccess) return fail(SSAL_EHIP, "batch_norm launch failed: %s", hipGetErrorString(e));
+    if (e2 != hipSuccess) return fail(SSAL_EHIP, "hipFreeAsync failed: %s", hipGetErrorString(e2));
+    return SSAL_OK;
+}
+
+SSAL_API int ssal_conv2d_same(const float *x_dev, int n, int h, int w, int cin,
+                              const float *kernel_dev, int kh, int kw, int cout, int stride,
+                              int dilation, float *y_dev, void *stream)
+{
+    if (!x_dev || !kernel_dev || !y_dev) return fail(SSAL_EINVAL, "NULL device pointer");
+    if (n <= 0 || h <= 0 || w <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || dilation <= 0)
+        return fail(SSAL_EINVAL, "bad dims");
+    if (cin % 4 || cout <= 0 || cout > 256 || 256 % cout)
+        return fail(SSAL_EINVAL, "conv2d needs cin %% 4 == 0 and cout a power of two <= 256 (cin=%d cout=%d)", cin, cout);
+    ConvArgs a = conv_args(x_dev, n, h, w, cin, kernel_dev, kh, kw, cout, stride, dilation, y_dev);
+    HIP_TRY(launch_conv(a, (hipStream_t)stream));
+    return SSAL_OK;
+}
+
+SSAL_API int ssal_conv2d_transpose_3x3_s2(const float *x_dev, int n, int h, int w, int cin,
+                                          const float *kernel_dev, int cout, float *y_dev,
+                                          void *stream)
+{
+    if (!x_dev || !kernel_dev || !y_dev) return fail(SSAL_EINVAL, "NULL device pointer");
+    if (n <= 0 || h <= 0 || w <= 0) return fail(SSAL_EINVAL, "bad dims");
+    if (cin % 4 || cout <= 0 || cout > 256 || 256 % cout)
+        return fail(SSAL_EINVAL, "conv2d_transpose needs cin %% 4 == 0 and cout a power of two <= 256 (cin=%d cout=%d)", cin, cout);
+    // the kernel arrives in TF layout [3,3,cout,cin]; re-lay it out on the device copy
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<float> hw((size_t)9 * cout * cin);
+    HIP_TRY(hipMemcpyAsync(hw.data(), kernel_dev, hw.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::vector<float> wt = hwoi_to_hwio(hw, cout, cin);
+    float *dw = nullptr;
+    HIP_TRY(hipMalloc((void **)&dw, wt.size() * sizeof(float)));
+    hipError_t e = hipMemcpyAsync(dw, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = launch_convT(x_dev, n, h, w, cin, dw, cout, nullptr, nullptr, nullptr, y_dev, s);
+    hipError_t e2 = hipStreamSynchronize(s);
+    (void)hipFree(dw);
+    if (e != hipSuccess) return fail(SSAL_EHIP, "conv2d_transpose failed: %s", hipGetErrorString(e));
+    if (e2 != hipSuccess) return fail(SSAL_EHIP, "stream sync failed: %s", hipGetErrorString(e2));
+    return SSAL_OK;
+}
+
+SSAL_API int ssal_resize_bilinear(const float *x_dev, int n, int h, int w, int c, int oh, int ow,
+                                  float *y_dev, void *stream)
+{
+    if (!x_dev || !y_dev) return fail(SSAL_EINVAL, "NULL device pointer");
+    if (n <= 0 || h <= 0 || w <= 0 || c <= 0 || oh <= 0 || ow <= 0) return fail(SSAL_EINVAL, "bad dims");
+    HIP_TRY(launch_resize_bilinear(x_dev, n, h, w, c, oh, ow, y_dev, (hipStream_t)stream));
+    return SSAL_OK;
+}
+
+SSAL_API int ssal_synth_frames_nhwc(uint64_t seed, int64_t first_frame, int count, int h, int w,
+                                    int c, float *out_dev, void *stream)
+{
+    if (!out_dev) return fail(SSAL_EINVAL, "NULL device pointer");
+    if (count <= 0 || h <= 0 || w <= 0 || c <= 0 || h % 8 || w % 8)
+        return fail(SSAL_EINVAL, "bad dims count=%d h=%d w=%d c=%d (H, W must be divisible by 8)", count, h, w, c);
+    HIP_TRY(launch_synth_frames(seed, first_frame, count, h, w, c, out_dev, (hipStream_t)stream));
+    return SSAL_OK;
+}

@@ -1,0 +1,82 @@
+// ssal_internal.h -- launch wrappers shared between the kernel translation units and the C ABI.
+// gfx950 (MI355X / CDNA4) only.  All tensors fp32 NHWC unless noted.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ssal {
+
+// How the residual branch of an ENet bottleneck is merged in the epilogue of the expansion conv.
+enum ResMode : int {
+    RES_NONE = 0,    // no residual
+    RES_ADD = 1,     // y = prelu(v + res[same pixel])                     (Bottleneck, enet_modules.py:596-598)
+    RES_POOL = 2,    // y = prelu(v + maxpool2x2(res_src) zero-padded)     (Downsample, :927-937); writes 2-bit codes
+    RES_UNPOOL = 3,  // y = prelu(v + unpool(res_src, code))               (Upsample,   :1285-1291)
+};
+
+struct ConvArgs {
+    const float *x;      // [N,H,W,Cin]
+    const float *w;      // [KH,KW,Cin,Cout]  (HWIO)
+    float *y;            // [N,Ho,Wo,Cout]
+    int N, H, W, Cin, Cout, KH, KW, stride, dil;
+    int Ho, Wo, pad_t, pad_l;
+    // epilogue: folded batch-norm (nullable) then PReLU (nullable)
+    const float *scale, *shift, *alpha;
+    // residual merge
+    int res_mode;
+    const float *res;         // RES_ADD: [N,Ho,Wo,Cout]; RES_POOL: [N,2Ho,2Wo,res_C]; RES_UNPOOL: [N,Ho/2,Wo/2,Cout]
+    int res_C;
+    uint8_t *code_out;        // RES_POOL: [N,Ho,Wo,res_C], code = dy*2+dx of the first maximum
+    const uint8_t *code_in;   // RES_UNPOOL: [N,Ho/2,Wo/2,Cout]
+    const float *res_alpha;   // PReLU after the residual add
+};
+
+hipError_t launch_conv(const ConvArgs &a, hipStream_t s);
+
+// conv2d_transpose 3x3 stride 2 SAME.  wT is the re-laid-out kernel [3][3][Cin][Cout].
+hipError_t launch_convT(const float *x, int N, int H, int W, int Cin, const float *wT, int Cout,
+                        const float *scale, const float *shift, const float *alpha, float *y,
+                        hipStream_t s);
+
+// Initial block (enet_modules.py:190-224): concat[conv3x3 s2, maxpool2x2] -> BN -> PReLU, 16 channels out.
+hipError_t launch_initial(const float *x, int N, int H, int W, int Cin, const float *w,
+                          const float *scale, const float *shift, const float *alpha, float *y,
+                          hipStream_t s);
+
+// Final transposed conv (enet_modules.py:1359-1381) fused with the acquisition score
+// (active_learning.py:234-263).  wF is the re-laid-out kernel [3][3][16][K].
+// logits (nullable) [N,2H,2W,K]; partial: [N * final_score_blocks(H,W)] doubles.
+int final_score_blocks(int H, int W);
+hipError_t launch_final_score(const float *x, int N, int H, int W, const float *wF, int K,
+                              float *logits, int measure, float threshold, double *partial,
+                              uint8_t *label, uint8_t *mask, float *conf, hipStream_t s);
+// scores[n] = sum(partial[n, 0..blocks)) / pixels, fixed summation order (bitwise reproducible)
+hipError_t launch_reduce_mean(const double *partial, int N, int blocks, double pixels,
+                              double *scores, hipStream_t s);
+
+// stand-alone score on materialised logits [N,H,W,K]
+int score_blocks(int H, int W);
+hipError_t launch_score_logits(const float *logits, int N, int H, int W, int K, int measure,
+                               float threshold, double *partial, uint8_t *label, uint8_t *mask,
+                               float *conf, hipStream_t s);
+
+// pooling / unpooling with reference int64 indices
+hipError_t launch_maxpool_argmax(const float *x, int N, int H, int W, int C, float *y,
+                                 int64_t *argmax, int include_batch, hipStream_t s);
+hipError_t launch_unpool_scatter(const float *x, const int64_t *idx, int N, int H, int W, int C,
+                                 int idx_has_batch, float *y, hipStream_t s);
+hipError_t launch_codes_to_argmax(const uint8_t *code, int N, int Ho, int Wo, int C,
+                                  int64_t *argmax, hipStream_t s);
+
+hipError_t launch_prelu(const float *x, int64_t pixels, int C, const float *alpha, float *y,
+                        hipStream_t s);
+hipError_t launch_affine(const float *x, int64_t pixels, int C, const float *scale,
+                         const float *shift, float *y, hipStream_t s);
+hipError_t launch_bn_fold(const float *mean, const float *var, const float *gamma,
+                          const float *beta, int C, float *scale, float *shift, hipStream_t s);
+hipError_t launch_resize_bilinear(const float *x, int N, int H, int W, int C, int OH, int OW,
+                                  float *y, hipStream_t s);
+hipError_t launch_synth_frames(uint64_t seed, int64_t first, int count, int H, int W, int C,
+                               float *out, hipStream_t s);
+
+}  // namespace ssal

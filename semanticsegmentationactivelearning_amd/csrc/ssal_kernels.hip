@@ -1,0 +1,803 @@
+// ssal_kernels.hip -- generic (shape-agnostic) HIP kernels of the ENet pool-scoring path, gfx950.
+//
+// These are the correctness-first kernels: every conv output element is one fp32 fmaf chain over
+// (kh, kw, ci) in ascending order, exactly the order the parity oracle uses, so results are
+// bit-comparable.  Lanes run along the output-channel axis so weight loads and activation stores are
+// coalesced 128-B segments and the activation operand is a wave-broadcast float4.  The MFMA-tiled
+// bottleneck kernels (ssal_bottleneck_mfma.hip) replace these on the hot shapes; these remain the
+// path for the odd shapes (4-channel input, 4/8-wide bottlenecks) and the per-operator C ABI.
+//
+// Reference semantics restated per kernel (file:line relative to the reference repository).
+#include "ssal_internal.h"
+#include <float.h>
+
+namespace ssal {
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ float prelu_f(float v, float a) { return v >= 0.0f ? v : a * v; }
+
+// ------------------------------------------------------------------------------------------------
+// Initial block: concat[ conv3x3 s2 SAME (Cin -> 16-Cin), maxpool2x2 s2 (Cin) ] -> BN(16) -> PReLU(16)
+// (enet_modules.py:190-224; concat order conv first :214-215).  SAME on even H,W: pad (0 before, 1 after).
+// One thread per output pixel; kernel weights are wave-uniform (scalar loads).
+// ------------------------------------------------------------------------------------------------
+template <int CIN>
+__global__ __launch_bounds__(256) void k_initial(const float *__restrict__ x,
+                                                 const float *__restrict__ w,
+                                                 const float *__restrict__ scale,
+                                                 const float *__restrict__ shift,
+                                                 const float *__restrict__ alpha,
+                                                 float *__restrict__ y, int N, int H, int W)
+{
+    constexpr int CC = 16 - CIN;
+    const int Ho = H / 2, Wo = W / 2;
+    const long total = (long)N * Ho * Wo;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total;
+         p += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(p % Wo);
+        const int oy = (int)((p / Wo) % Ho);
+        const int n = (int)(p / ((long)Wo * Ho));
+        float acc[CC];
+#pragma unroll
+        for (int c = 0; c < CC; ++c) acc[c] = 0.0f;
+        float best[CIN];
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) best[c] = -FLT_MAX;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int iy = 2 * oy + kh;
+            if (iy >= H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ix = 2 * ox + kw;
+                if (ix >= W) continue;
+                const float *xp = x + (((long)n * H + iy) * W + ix) * CIN;
+                float xv[CIN];
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) xv[ci] = xp[ci];
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) {
+                    const float *wr = w + ((kh * 3 + kw) * CIN + ci) * CC;
+#pragma unroll
+                    for (int co = 0; co < CC; ++co) acc[co] = fmaf(xv[ci], wr[co], acc[co]);
+                }
+                if (kh < 2 && kw < 2) {  // 2x2 pooling window, (y,x) order, strict '>'
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci)
+                        if (xv[ci] > best[ci]) best[ci] = xv[ci];
+                }
+            }
+        }
+        float out[16];
+#pragma unroll
+        for (int c = 0; c < CC; ++c) out[c] = acc[c];
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) out[CC + c] = best[c];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) out[c] = prelu_f(fmaf(out[c], scale[c], shift[c]), alpha[c]);
+        float4 *yp = reinterpret_cast<float4 *>(y + p * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            yp[q] = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+    }
+}
+
+hipError_t launch_initial(const float *x, int N, int H, int W, int Cin, const float *w,
+                          const float *scale, const float *shift, const float *alpha, float *y,
+                          hipStream_t s)
+{
+    const long total = (long)N * (H / 2) * (W / 2);
+    const int grid = cdiv(total, 256);
+    if (Cin == 3)
+        hipLaunchKernelGGL(k_initial<3>, dim3(grid), dim3(256), 0, s, x, w, scale, shift, alpha, y, N, H, W);
+    else if (Cin == 4)
+        hipLaunchKernelGGL(k_initial<4>, dim3(grid), dim3(256), 0, s, x, w, scale, shift, alpha, y, N, H, W);
+    else if (Cin == 1)
+        hipLaunchKernelGGL(k_initial<1>, dim3(grid), dim3(256), 0, s, x, w, scale, shift, alpha, y, N, H, W);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic tf.nn.conv2d "SAME" (cross-correlation, NHWC x HWIO) with fused epilogue:
+//   v = acc; [v = fmaf(v, scale, shift)]; [v = prelu(v, alpha)];
+//   residual merge (ResMode); [v = prelu(v, res_alpha)]
+// thread <-> (pixel group of PX consecutive ox, output channel); lanes run along co.
+// Requires Cin % 4 == 0 and 256 % Cout == 0.
+// ------------------------------------------------------------------------------------------------
+template <int PX>
+__global__ __launch_bounds__(256) void k_conv(ConvArgs a)
+{
+    const int tid = threadIdx.x;
+    const int co = tid % a.Cout;
+    const int gpb = 256 / a.Cout;
+    const int gx = (a.Wo + PX - 1) / PX;
+    const long ngroups = (long)a.N * a.Ho * gx;
+    const long g = (long)blockIdx.x * gpb + tid / a.Cout;
+    if (g >= ngroups) return;
+    const int gxi = (int)(g % gx);
+    const int oy = (int)((g / gx) % a.Ho);
+    const int n = (int)(g / ((long)gx * a.Ho));
+    const int ox0 = gxi * PX;
+
+    float acc[PX];
+#pragma unroll
+    for (int i = 0; i < PX; ++i) acc[i] = 0.0f;
+
+    for (int kh = 0; kh < a.KH; ++kh) {
+        const int iy = oy * a.stride - a.pad_t + kh * a.dil;
+        if (iy < 0 || iy >= a.H) continue;
+        const float *xrow = a.x + ((long)n * a.H + iy) * a.W * a.Cin;
+        for (int kw = 0; kw < a.KW; ++kw) {
+            const int ixb = ox0 * a.stride - a.pad_l + kw * a.dil;
+            const float *wp = a.w + (long)((kh * a.KW + kw) * a.Cin) * a.Cout + co;
+            bool ok[PX];
+#pragma unroll
+            for (int i = 0; i < PX; ++i) {
+                const int ix = ixb + i * a.stride;
+                ok[i] = (ix >= 0) && (ix < a.W) && (ox0 + i < a.Wo);
+            }
+            for (int ci = 0; ci < a.Cin; ci += 4) {
+                const float w0 = wp[(long)(ci + 0) * a.Cout];
+                const float w1 = wp[(long)(ci + 1) * a.Cout];
+                const float w2 = wp[(long)(ci + 2) * a.Cout];
+                const float w3 = wp[(long)(ci + 3) * a.Cout];
+#pragma unroll
+                for (int i = 0; i < PX; ++i) {
+                    if (ok[i]) {
+                        const int ix = ixb + i * a.stride;
+                        const float4 v =
+                            *reinterpret_cast<const float4 *>(xrow + (long)ix * a.Cin + ci);
+                        acc[i] = fmaf(v.x, w0, acc[i]);
+                        acc[i] = fmaf(v.y, w1, acc[i]);
+                        acc[i] = fmaf(v.z, w2, acc[i]);
+                        acc[i] = fmaf(v.w, w3, acc[i]);
+                    }
+                }
+            }
+        }
+    }
+
+    const float sc = a.scale ? a.scale[co] : 1.0f;
+    const float sh = a.scale ? a.shift[co] : 0.0f;
+    const float al = a.alpha ? a.alpha[co] : 0.0f;
+    const float ral = a.res_alpha ? a.res_alpha[co] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+        const int ox = ox0 + i;
+        if (ox >= a.Wo) break;
+        float v = acc[i];
+        if (a.scale) v = fmaf(v, sc, sh);
+        if (a.alpha) v = prelu_f(v, al);
+        const long opix = ((long)n * a.Ho + oy) * a.Wo + ox;
+        if (a.res_mode == RES_ADD) {
+            v = v + a.res[opix * a.Cout + co];
+        } else if (a.res_mode == RES_POOL) {
+            // tf.nn.max_pool_with_argmax 2x2/s2 on the block input, zero-padded in channels at the end
+            // (enet_modules.py:927-933).  First maximum in (y,x) order wins (strict '>').
+            if (co < a.res_C) {
+                const int Hs = 2 * a.Ho, Ws = 2 * a.Wo;
+                float best = -FLT_MAX;
+                int code = 0;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int iy = 2 * oy + (d >> 1), ix = 2 * ox + (d & 1);
+                    const float r = a.res[(((long)n * Hs + iy) * Ws + ix) * a.res_C + co];
+                    if (r > best) { best = r; code = d; }
+                }
+                a.code_out[opix * a.res_C + co] = (uint8_t)code;
+                v = v + best;
+            }
+        } else if (a.res_mode == RES_UNPOOL) {
+            // unpool_2d as a gather: every 2x2/s2 pooling index lies inside its own window, so
+            // scatter_nd into zeros (extra_ops.py:82-85) == select on the saved window code.
+            const int Hs = a.Ho / 2, Ws = a.Wo / 2;
+            const long sp = (((long)n * Hs + (oy >> 1)) * Ws + (ox >> 1)) * a.Cout + co;
+            const int code = a.code_in[sp];
+            const float r = (code == ((oy & 1) * 2 + (ox & 1))) ? a.res[sp] : 0.0f;
+            v = v + r;
+        }
+        if (a.res_alpha) v = prelu_f(v, ral);
+        a.y[opix * a.Cout + co] = v;
+    }
+}
+
+hipError_t launch_conv(const ConvArgs &a, hipStream_t s)
+{
+    if (a.Cin % 4 != 0 || a.Cout <= 0 || a.Cout > 256 || 256 % a.Cout != 0) return hipErrorInvalidValue;
+    constexpr int PX = 4;
+    const int gx = (a.Wo + PX - 1) / PX;
+    const long ngroups = (long)a.N * a.Ho * gx;
+    const int gpb = 256 / a.Cout;
+    const long grid = (ngroups + gpb - 1) / gpb;
+    if (grid <= 0 || grid > 0x7fffffffL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_conv<PX>, dim3((unsigned)grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// tf.nn.conv2d_transpose 3x3 / stride 2 / SAME -> [N,2H,2W,Cout]  (enet_modules.py:1251-1255)
+//   out[2i+kh, 2j+kw, o] += in[i,j,c] * W[kh,kw,o,c]; rows/cols 2H / 2W dropped   
+// gather form, taps (kh,kw,ci) ascending; wT = [3][3][Cin][Cout]; fused BN + PReLU (nullable).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_convT(const float *__restrict__ x, int N, int H, int W,
+                                               int Cin, const float *__restrict__ wT, int Cout,
+                                               const float *__restrict__ scale,
+                                               const float *__restrict__ shift,
+                                               const float *__restrict__ alpha,
+                                               float *__restrict__ y)
+{
+    const int tid = threadIdx.x;
+    const int co = tid % Cout;
+    const int ppb = 256 / Cout;
+    const int Ho = 2 * H, Wo = 2 * W;
+    const long npix = (long)N * Ho * Wo;
+    const long p = (long)blockIdx.x * ppb + tid / Cout;
+    if (p >= npix) return;
+    const int ox = (int)(p % Wo);
+    const int oy = (int)((p / Wo) % Ho);
+    const int n = (int)(p / ((long)Wo * Ho));
+    float acc = 0.0f;
+    for (int kh = 0; kh < 3; ++kh) {
+        const int ty = oy - kh;
+        if (ty < 0 || (ty & 1)) continue;
+        const int iy = ty >> 1;
+        if (iy >= H) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+            const int tx = ox - kw;
+            if (tx < 0 || (tx & 1)) continue;
+            const int ix = tx >> 1;
+            if (ix >= W) continue;
+            const float *xp = x + (((long)n * H + iy) * W + ix) * Cin;
+            const float *wp = wT + (long)((kh * 3 + kw) * Cin) * Cout + co;
+            for (int ci = 0; ci < Cin; ci += 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(xp + ci);
+                acc = fmaf(v.x, wp[(long)(ci + 0) * Cout], acc);
+                acc = fmaf(v.y, wp[(long)(ci + 1) * Cout], acc);
+                acc = fmaf(v.z, wp[(long)(ci + 2) * Cout], acc);
+                acc = fmaf(v.w, wp[(long)(ci + 3) * Cout], acc);
+            }
+        }
+    }
+    float v = acc;
+    if (scale) v = fmaf(v, scale[co], shift[co]);
+    if (alpha) v = prelu_f(v, alpha[co]);
+    y[p * Cout + co] = v;
+}
+
+hipError_t launch_convT(const float *x, int N, int H, int W, int Cin, const float *wT, int Cout,
+                        const float *scale, const float *shift, const float *alpha, float *y,
+                        hipStream_t s)
+{
+    if (Cin % 4 != 0 || Cout <= 0 || Cout > 256 || 256 % Cout != 0) return hipErrorInvalidValue;
+    const long npix = (long)N * 4 * H * W;
+    const int ppb = 256 / Cout;
+    const long grid = (npix + ppb - 1) / ppb;
+    if (grid <= 0 || grid > 0x7fffffffL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_convT, dim3((unsigned)grid), dim3(256), 0, s, x, N, H, W, Cin, wT, Cout,
+                       scale, shift, alpha, y);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-pixel acquisition score (active_learning.py:239-260) on K logits held in registers.
+//   softmax: p_k = exp(x_k - m) / S,  S = sum_k exp(x_k - m)
+//   entropy   : conf = 1 - H/log(K),  H = -sum p log p = log S - sum_k e_k (x_k - m) / S
+//               (the reference adds FLT_MIN inside the log; it changes H by < 1e-36)
+//   margin    : conf = p_(1) - p_(2) = (1 - e_(2)) / S
+//   confidence: conf = p_(1) = 1 / S
+// label = first maximum of the logits (tf.math.argmax, :234-236).
+// ------------------------------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ float pixel_score(const float (&l)[K], int measure, float inv_logK,
+                                             int &label)
+{
+    float m = l[0];
+    int am = 0;
+#pragma unroll
+    for (int k = 1; k < K; ++k)
+        if (l[k] > m) { m = l[k]; am = k; }
+    label = am;
+    float S = 0.0f, T = 0.0f, e2 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float d = l[k] - m;
+        const float e = __expf(d);
+        S += e;
+        T = fmaf(e, d, T);
+        if (k != am && e > e2) e2 = e;
+    }
+    if (measure == 0) {
+        const float Hn = __logf(S) - T / S;
+        return 1.0f - Hn * inv_logK;
+    } else if (measure == 1) {
+        return (1.0f - e2) / S;
+    }
+    return 1.0f / S;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// block-wide fp64 sum, result valid in thread 0 (256 threads = 4 waves)
+__device__ __forceinline__ double block_sum_256(double v, double *lds4)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) lds4[wid] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) r = ((lds4[0] + lds4[1]) + lds4[2]) + lds4[3];
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Final (conv2d_transpose 3x3 s2, 16 -> K, no bias/BN/activation; enet_modules.py:1359-1381) fused
+// with the score.  One thread per INPUT pixel (i,j) = one 2x2 output quad, so the kernel taps of
+// every output parity are wave-uniform (scalar loads) and there is no divergence:
+//   out(2i  ,2j  ) = a*W00 + c*W02 + b*W20 + d*W22     a=in(i,j) b=in(i-1,j) c=in(i,j-1) d=in(i-1,j-1)
+//   out(2i  ,2j+1) = a*W01 + b*W21
+//   out(2i+1,2j  ) = a*W10 + c*W12
+//   out(2i+1,2j+1) = a*W11                      (taps listed in (kh,kw) ascending = oracle order)
+// wF = [3][3][16][K].  grid = (ceil(H*W/256), N): a block never straddles two images.
+// ------------------------------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ void tap16(float (&acc)[K], const float (&v)[16],
+                                      const float *__restrict__ wtap)
+{
+#pragma unroll
+    for (int ci = 0; ci < 16; ++ci) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = fmaf(v[ci], wtap[ci * K + k], acc[k]);
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void k_final_score(const float *__restrict__ x, int N, int H,
+                                                     int W, const float *__restrict__ wF,
+                                                     float *__restrict__ logits, int measure,
+                                                     float threshold, double *__restrict__ partial,
+                                                     uint8_t *__restrict__ label,
+                                                     uint8_t *__restrict__ mask,
+                                                     float *__restrict__ conf)
+{
+    __shared__ double red[4];
+    const int n = blockIdx.y;
+    const long HW = (long)H * W;
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = p < HW;
+    double local = 0.0;
+    if (valid) {
+        const int i = (int)(p / W), j = (int)(p % W);
+        float va[16], vb[16], vc[16], vd[16];
+        const float *xa = x + ((long)n * HW + p) * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 t = reinterpret_cast<const float4 *>(xa)[q];
+            va[4 * q] = t.x; va[4 * q + 1] = t.y; va[4 * q + 2] = t.z; va[4 * q + 3] = t.w;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i > 0) t = reinterpret_cast<const float4 *>(xa - (long)W * 16)[q];
+            vb[4 * q] = t.x; vb[4 * q + 1] = t.y; vb[4 * q + 2] = t.z; vb[4 * q + 3] = t.w;
+            t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j > 0) t = reinterpret_cast<const float4 *>(xa - 16)[q];
+            vc[4 * q] = t.x; vc[4 * q + 1] = t.y; vc[4 * q + 2] = t.z; vc[4 * q + 3] = t.w;
+            t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i > 0 && j > 0) t = reinterpret_cast<const float4 *>(xa - (long)W * 16 - 16)[q];
+            vd[4 * q] = t.x; vd[4 * q + 1] = t.y; vd[4 * q + 2] = t.z; vd[4 * q + 3] = t.w;
+        }
+        const float inv_logK = 1.0f / __logf((float)K);
+        const int Wo = 2 * W;
+#pragma unroll
+        for (int quad = 0; quad < 4; ++quad) {
+            float acc[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[k] = 0.0f;
+            if (quad == 0) {  // (even, even): taps (0,0) a, (0,2) c, (2,0) b, (2,2) d
+                tap16<K>(acc, va, wF + (0 * 3 + 0) * 16 * K);
+                tap16<K>(acc, vc, wF + (0 * 3 + 2) * 16 * K);
+                tap16<K>(acc, vb, wF + (2 * 3 + 0) * 16 * K);
+                tap16<K>(acc, vd, wF + (2 * 3 + 2) * 16 * K);
+            } else if (quad == 1) {  // (even, odd): (0,1) a, (2,1) b
+                tap16<K>(acc, va, wF + (0 * 3 + 1) * 16 * K);
+                tap16<K>(acc, vb, wF + (2 * 3 + 1) * 16 * K);
+            } else if (quad == 2) {  // (odd, even): (1,0) a, (1,2) c
+                tap16<K>(acc, va, wF + (1 * 3 + 0) * 16 * K);
+                tap16<K>(acc, vc, wF + (1 * 3 + 2) * 16 * K);
+            } else {  // (odd, odd): (1,1) a
+                tap16<K>(acc, va, wF + (1 * 3 + 1) * 16 * K);
+            }
+            const int oy = 2 * i + (quad >> 1), ox = 2 * j + (quad & 1);
+            const long op = ((long)n * 2 * H + oy) * Wo + ox;
+            if (logits) {
+                float *lp = logits + op * K;
+#pragma unroll
+                for (int k = 0; k < K; ++k) lp[k] = acc[k];
+            }
+            int lab;
+            const float cf = pixel_score<K>(acc, measure, inv_logK, lab);
+            local += (double)cf;
+            if (label) label[op] = (uint8_t)lab;
+            if (mask) mask[op] = cf < threshold ? (uint8_t)0 : (uint8_t)1;
+            if (conf) conf[op] = cf;
+        }
+    }
+    const double r = block_sum_256(local, red);
+    if (threadIdx.x == 0) partial[(long)n * gridDim.x + blockIdx.x] = r;
+}
+
+int final_score_blocks(int H, int W) { return cdiv((long)H * W, 256); }
+
+hipError_t launch_final_score(const float *x, int N, int H, int W, const float *wF, int K,
+                              float *logits, int measure, float threshold, double *partial,
+                              uint8_t *label, uint8_t *mask, float *conf, hipStream_t s)
+{
+    dim3 grid(final_score_blocks(H, W), N), block(256);
+#define SSAL_FS(KK)                                                                               \
+    case KK:                                                                                      \
+        hipLaunchKernelGGL(k_final_score<KK>, grid, block, 0, s, x, N, H, W, wF, logits, measure, \
+                           threshold, partial, label, mask, conf);                                \
+        break;
+    switch (K) {
+        SSAL_FS(2) SSAL_FS(3) SSAL_FS(4) SSAL_FS(5) SSAL_FS(6) SSAL_FS(7) SSAL_FS(8) SSAL_FS(9)
+        SSAL_FS(10) SSAL_FS(11) SSAL_FS(12) SSAL_FS(13) SSAL_FS(14) SSAL_FS(15) SSAL_FS(16)
+        SSAL_FS(17) SSAL_FS(18) SSAL_FS(19) SSAL_FS(20) SSAL_FS(21) SSAL_FS(22) SSAL_FS(23)
+        SSAL_FS(24) SSAL_FS(25) SSAL_FS(26) SSAL_FS(27) SSAL_FS(28) SSAL_FS(29) SSAL_FS(30)
+        SSAL_FS(31) SSAL_FS(32)
+    default:
+        return hipErrorInvalidValue;
+    }
+#undef SSAL_FS
+    return hipGetLastError();
+}
+
+// scores[n] = (sum of partial[n,:]) / pixels; one block per image; fixed order => reproducible.
+__global__ __launch_bounds__(256) void k_reduce_mean(const double *__restrict__ partial, int blocks,
+                                                     double pixels, double *__restrict__ scores)
+{
+    __shared__ double red[4];
+    const int n = blockIdx.x;
+    double v = 0.0;
+    for (int b = threadIdx.x; b < blocks; b += 256) v += partial[(long)n * blocks + b];
+    const double r = block_sum_256(v, red);
+    if (threadIdx.x == 0) scores[n] = r / pixels;
+}
+
+hipError_t launch_reduce_mean(const double *partial, int N, int blocks, double pixels,
+                              double *scores, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_reduce_mean, dim3(N), dim3(256), 0, s, partial, blocks, pixels, scores);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stand-alone score on materialised logits [N,H,W,K] (HBM-bound: K*4 B read per pixel, ~0 written).
+// A block stages 256 pixels x K floats through LDS with coalesced float4 loads; each thread then
+// reads its own pixel's K logits at stride K dwords (bank-conflict-free for odd K, 2-way for even).
+// ------------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void k_score_logits(const float *__restrict__ logits, int N,
+                                                      long HW, int measure, float threshold,
+                                                      double *__restrict__ partial,
+                                                      uint8_t *__restrict__ label,
+                                                      uint8_t *__restrict__ mask,
+                                                      float *__restrict__ conf)
+{
+    constexpr int KP = (K % 2 == 0) ? K + 1 : K;  // odd LDS stride
+    __shared__ float tile[256 * KP];
+    __shared__ double red[4];
+    const int n = blockIdx.y;
+    const long p0 = (long)blockIdx.x * 256;
+    const int npx = (int)((HW - p0) < 256 ? (HW - p0) : 256);
+    const float *src = logits + ((long)n * HW + p0) * K;  // 256*K*4 B block offset: 16-B aligned
+    const int nflt = npx * K;
+    for (int f = threadIdx.x * 4; f < nflt; f += 1024) {
+        if (f + 3 < nflt) {
+            const float4 t = *reinterpret_cast<const float4 *>(src + f);
+            const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = f + q;
+                tile[(e / K) * KP + (e % K)] = tv[q];
+            }
+        } else {
+            for (int e = f; e < nflt; ++e) tile[(e / K) * KP + (e % K)] = src[e];
+        }
+    }
+    __syncthreads();
+    double local = 0.0;
+    if ((int)threadIdx.x < npx) {
+        float l[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) l[k] = tile[threadIdx.x * KP + k];
+        int lab;
+        const float cf = pixel_score<K>(l, measure, 1.0f / __logf((float)K), lab);
+        local = (double)cf;
+        const long op = (long)n * HW + p0 + threadIdx.x;
+        if (label) label[op] = (uint8_t)lab;
+        if (mask) mask[op] = cf < threshold ? (uint8_t)0 : (uint8_t)1;
+        if (conf) conf[op] = cf;
+    }
+    const double r = block_sum_256(local, red);
+    if (threadIdx.x == 0) partial[(long)n * gridDim.x + blockIdx.x] = r;
+}
+
+int score_blocks(int H, int W) { return cdiv((long)H * W, 256); }
+
+hipError_t launch_score_logits(const float *logits, int N, int H, int W, int K, int measure,
+                               float threshold, double *partial, uint8_t *label, uint8_t *mask,
+                               float *conf, hipStream_t s)
+{
+    dim3 grid(score_blocks(H, W), N), block(256);
+    const long HW = (long)H * W;
+#define SSAL_SL(KK)                                                                              \
+    case KK:                                                                                     \
+        hipLaunchKernelGGL(k_score_logits<KK>, grid, block, 0, s, logits, N, HW, measure,        \
+                           threshold, partial, label, mask, conf);                               \
+        break;
+    switch (K) {
+        SSAL_SL(2) SSAL_SL(3) SSAL_SL(4) SSAL_SL(5) SSAL_SL(6) SSAL_SL(7) SSAL_SL(8) SSAL_SL(9)
+        SSAL_SL(10) SSAL_SL(11) SSAL_SL(12) SSAL_SL(13) SSAL_SL(14) SSAL_SL(15) SSAL_SL(16)
+        SSAL_SL(17) SSAL_SL(18) SSAL_SL(19) SSAL_SL(20) SSAL_SL(21) SSAL_SL(22) SSAL_SL(23)
+        SSAL_SL(24) SSAL_SL(25) SSAL_SL(26) SSAL_SL(27) SSAL_SL(28) SSAL_SL(29) SSAL_SL(30)
+        SSAL_SL(31) SSAL_SL(32)
+    default:
+        return hipErrorInvalidValue;
+    }
+#undef SSAL_SL
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// tf.nn.max_pool_with_argmax 2x2/s2 with the reference's int64 index and the scatter
+// form of xops.unpool_2d (extra_ops.py:28-86) for arbitrary index tensors.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_maxpool_argmax(const float *__restrict__ x, int N, int H,
+                                                        int W, int C, float *__restrict__ y,
+                                                        int64_t *__restrict__ argmax,
+                                                        int include_batch)
+{
+    const int Ho = H / 2, Wo = W / 2;
+    const long total = (long)N * Ho * Wo * C;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
+        const int c = (int)(o % C);
+        const long pix = o / C;
+        const int ox = (int)(pix % Wo);
+        const int oy = (int)((pix / Wo) % Ho);
+        const int n = (int)(pix / ((long)Wo * Ho));
+        float best = -FLT_MAX;
+        long bi = -1;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int iy = 2 * oy + (d >> 1), ix = 2 * ox + (d & 1);
+            const float v = x[(((long)n * H + iy) * W + ix) * C + c];
+            if (v > best) { best = v; bi = ((long)iy * W + ix) * C + c; }
+        }
+        y[o] = best;
+        if (argmax) argmax[o] = bi + (include_batch ? (long)n * H * W * C : 0L);
+    }
+}
+
+hipError_t launch_maxpool_argmax(const float *x, int N, int H, int W, int C, float *y,
+                                 int64_t *argmax, int include_batch, hipStream_t s)
+{
+    const long total = (long)N * (H / 2) * (W / 2) * C;
+    int grid = cdiv(total, 256);
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(k_maxpool_argmax, dim3(grid), dim3(256), 0, s, x, N, H, W, C, y, argmax,
+                       include_batch);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_unpool_scatter(const float *__restrict__ x,
+                                                        const int64_t *__restrict__ idx, long per_img_in,
+                                                        long total_in, long per_img_out, long total_out,
+                                                        int idx_has_batch, float *__restrict__ y)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total_in; i += (long)gridDim.x * 256) {
+        const long n = i / per_img_in;
+        const long k = idx[i] + (idx_has_batch ? 0L : n * per_img_out);
+        if (k >= 0 && k < total_out) y[k] = x[i];  // out-of-range indices are dropped, never written
+    }
+}
+
+hipError_t launch_unpool_scatter(const float *x, const int64_t *idx, int N, int H, int W, int C,
+                                 int idx_has_batch, float *y, hipStream_t s)
+{
+    const long per_in = (long)H * W * C, per_out = 4 * per_in;
+    hipError_t e = hipMemsetAsync(y, 0, sizeof(float) * per_out * N, s);
+    if (e != hipSuccess) return e;
+    int grid = cdiv(per_in * N, 256);
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(k_unpool_scatter, dim3(grid), dim3(256), 0, s, x, idx, per_in, per_in * N,
+                       per_out, per_out * N, idx_has_batch, y);
+    return hipGetLastError();
+}
+
+// window code (dy*2+dx) at pooled position -> reference int64 index into the un-pooled [2Ho,2Wo,C] image
+__global__ __launch_bounds__(256) void k_codes_to_argmax(const uint8_t *__restrict__ code, int N,
+                                                         int Ho, int Wo, int C,
+                                                         int64_t *__restrict__ argmax)
+{
+    const long total = (long)N * Ho * Wo * C;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
+        const int c = (int)(o % C);
+        const long pix = o / C;
+        const int ox = (int)(pix % Wo);
+        const int oy = (int)((pix / Wo) % Ho);
+        const int d = code[o];
+        argmax[o] = ((long)(2 * oy + (d >> 1)) * (2 * Wo) + (2 * ox + (d & 1))) * C + c;
+    }
+}
+
+hipError_t launch_codes_to_argmax(const uint8_t *code, int N, int Ho, int Wo, int C,
+                                  int64_t *argmax, hipStream_t s)
+{
+    const long total = (long)N * Ho * Wo * C;
+    int grid = cdiv(total, 256);
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(k_codes_to_argmax, dim3(grid), dim3(256), 0, s, code, N, Ho, Wo, C, argmax);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Elementwise operators of models/util/extra_ops.py exposed through the C ABI.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_prelu(const float *__restrict__ x, long total, int C,
+                                               const float *__restrict__ alpha,
+                                               float *__restrict__ y)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256)
+        y[i] = prelu_f(x[i], alpha[i % C]);
+}
+
+hipError_t launch_prelu(const float *x, int64_t pixels, int C, const float *alpha, float *y,
+                        hipStream_t s)
+{
+    const long total = pixels * C;
+    int grid = cdiv(total, 256);
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(k_prelu, dim3(grid), dim3(256), 0, s, x, total, C, alpha, y);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_affine(const float *__restrict__ x, long total, int C,
+                                                const float *__restrict__ scale,
+                                                const float *__restrict__ shift,
+                                                float *__restrict__ y)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        y[i] = fmaf(x[i], scale[c], shift[c]);
+    }
+}
+
+hipError_t launch_affine(const float *x, int64_t pixels, int C, const float *scale,
+                         const float *shift, float *y, hipStream_t s)
+{
+    const long total = pixels * C;
+    int grid = cdiv(total, 256);
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(k_affine, dim3(grid), dim3(256), 0, s, x, total, C, scale, shift, y);
+    return hipGetLastError();
+}
+
+// tf.nn.fused_batch_norm(is_training=False), eps = 1e-3 (extra_ops.py:181-184) folded to (scale, shift)
+__global__ void k_bn_fold(const float *__restrict__ mean, const float *__restrict__ var,
+                          const float *__restrict__ gamma, const float *__restrict__ beta, int C,
+                          float *__restrict__ scale, float *__restrict__ shift)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const float sgm = gamma[c] / sqrtf(var[c] + 1e-3f);
+        scale[c] = sgm;
+        shift[c] = fmaf(-mean[c], sgm, beta[c]);
+    }
+}
+
+hipError_t launch_bn_fold(const float *mean, const float *var, const float *gamma,
+                          const float *beta, int C, float *scale, float *shift, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_bn_fold, dim3(cdiv(C, 64)), dim3(64), 0, s, mean, var, gamma, beta, C,
+                       scale, shift);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// tf.image.resize_bilinear, TF-1.13 defaults: align_corners=False, legacy mapping
+// src = dst * (in/out) (no half-pixel offset); lerp in fp32:  top + (bottom - top) * y_lerp, where
+// top = tl + (tr - tl) * x_lerp   (inference.py:96-99).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize_bilinear(const float *__restrict__ x, int N, int H,
+                                                         int W, int C, int OH, int OW,
+                                                         float hs, float ws, float *__restrict__ y)
+{
+    const long total = (long)N * OH * OW * C;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
+        const int c = (int)(o % C);
+        const long pix = o / C;
+        const int ox = (int)(pix % OW);
+        const int oy = (int)((pix / OW) % OH);
+        const int n = (int)(pix / ((long)OW * OH));
+        const float fy = (float)oy * hs, fx = (float)ox * ws;
+        const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+        const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float *img = x + (long)n * H * W * C;
+        const float tl = img[((long)y0 * W + x0) * C + c], tr = img[((long)y0 * W + x1) * C + c];
+        const float bl = img[((long)y1 * W + x0) * C + c], br = img[((long)y1 * W + x1) * C + c];
+        const float top = tl + (tr - tl) * lx;
+        const float bot = bl + (br - bl) * lx;
+        y[o] = top + (bot - top) * ly;
+    }
+}
+
+hipError_t launch_resize_bilinear(const float *x, int N, int H, int W, int C, int OH, int OW,
+                                  float *y, hipStream_t s)
+{
+    const long total = (long)N * OH * OW * C;
+    int grid = cdiv(total, 256);
+    if (grid > 65536) grid = 65536;
+    const float hs = (float)H / (float)OH, ws = (float)W / (float)OW;
+    hipLaunchKernelGGL(k_resize_bilinear, dim3(grid), dim3(256), 0, s, x, N, H, W, C, OH, OW, hs,
+                       ws, y);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Synthetic frames: counter-based, so frame f is a pure function of (seed, f) on host
+// and device alike (host twin: synthetic.py).  coarse 8x8 blocks + fine noise, per-frame brightness.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void k_synth_frames(uint64_t seed, long first, int count, int H,
+                                                      int W, int C, float *__restrict__ out)
+{
+    const long per = (long)H * W * C;
+    const long total = per * count;
+    const int Wc = W / 8;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
+        const long f = first + o / per;
+        const long r = o % per;
+        const int c = (int)(r % C);
+        const long pix = r / C;
+        const int xx = (int)(pix % W), yy = (int)(pix / W);
+        const uint64_t fk = splitmix64(seed ^ ((uint64_t)f * 0xD1342543DE82EF95ull));
+        const float u = (float)(splitmix64(fk ^ 0xB5ull) >> 40) * (1.0f / 16777216.0f);
+        const float bright = 0.2f + 0.8f * u;
+        const uint64_t ic = (uint64_t)(((long)(yy / 8) * Wc + (xx / 8)) * C + c);
+        const int coarse = (int)(splitmix64(fk + 2ull * ic) >> 56);
+        const int fine = (int)((splitmix64(fk + 2ull * (uint64_t)r + 1ull) >> 32) % 33ull) - 16;
+        float v = (float)(coarse + fine) * bright;
+        v = fminf(fmaxf(v, 0.0f), 255.0f);
+        const int u8 = (int)v;
+        out[o] = (float)u8 * (1.0f / 255.0f);
+    }
+}
+
+hipError_t launch_synth_frames(uint64_t seed, int64_t first, int count, int H, int W, int C,
+                               float *out, hipStream_t s)
+{
+    const long total = (long)H * W * C * count;
+    int grid = cdiv(total, 256);
+    if (grid > 262144) grid = 262144;
+    hipLaunchKernelGGL(k_synth_frames, dim3(grid), dim3(256), 0, s, seed, (long)first, count, H, W,
+                       C, out);
+    return hipGetLastError();
+}
+
+}  // namespace ssal

@@ -1,0 +1,255 @@
+"""ENet model: host-side mirror of the reference's ``models.ENet`` (models/enet/enet.py:6-407).
+
+``ENet(classes, ...)(inputs_NHWC_f32, training=False) -> logits [N,H,W,classes]`` keeps the
+reference operator API (constructor kwargs, sub-layer attribute names, weight names/layouts,
+``.layers[i].variables[j]``, ``.Final.kernel``, ``.endpoint_outputs``).  The forward pass runs the
+hand-written HIP kernels of libssal_hip.so through the C ABI on the current HIP stream; tensors
+are torch tensors resident on the MI355X.  ``score()`` is the fused pool-scoring entry
+(forward + softmax + acquisition measure + fp64 per-image mean; logits never reach HBM).
+"""
+import ctypes
+
+from ... import _lib
+from . import enet_modules as mod
+
+
+class ENet:
+    """https://arxiv.org/pdf/1606.02147.pdf"""
+
+    def __init__(self, classes,
+                 kernel_initializer=None,
+                 alpha_initializer=None,
+                 weight_regularization=None,
+                 regularization_scaling=False,
+                 drop_rates=[0.01, 0.1, 0.1, 0.1, 0.1],
+                 name="ENet"):
+        if len(drop_rates) != 5:
+            raise ValueError("Illegal argument value @drop_rates, length must be 5.")
+        self.classes = classes
+        self.name = name
+        self.built = False
+        kernel_initializer = kernel_initializer or mod.glorot_uniform()
+        alpha_initializer = alpha_initializer or mod.constant(0.25)
+        kw = dict(kernel_initializer=kernel_initializer, alpha_initializer=alpha_initializer,
+                  kernel_regularizer=weight_regularization,
+                  regularization_scaling=regularization_scaling)
+
+        # reference models/enet/enet.py:35-247
+        self.Initial = mod.Initial(16, name="Initial", **kw)
+        # Stage 1
+        self.Bottleneck1_0 = mod.BottleneckDownsample(64, name="Bottleneck1_0", drop_rate=drop_rates[0], **kw)
+        for i in range(1, 5):
+            setattr(self, "Bottleneck1_%d" % i,
+                    mod.Bottleneck(64, name="Bottleneck1_%d" % i, drop_rate=drop_rates[0], **kw))
+        # Stage 2 / 3
+        self.Bottleneck2_0 = mod.BottleneckDownsample(128, name="Bottleneck2_0", drop_rate=drop_rates[1], **kw)
+        variants = {1: {}, 2: dict(dilation_rate=(2, 2)), 3: dict(asymmetric=True, kernel_size=(5, 5)),
+                    4: dict(dilation_rate=(4, 4)), 5: {}, 6: dict(dilation_rate=(8, 8)),
+                    7: dict(asymmetric=True, kernel_size=(5, 5)), 8: dict(dilation_rate=(16, 16))}
+        for stage, rate in ((2, drop_rates[1]), (3, drop_rates[2])):
+            for i in range(1, 9):
+                nm = "Bottleneck%d_%d" % (stage, i)
+                setattr(self, nm, mod.Bottleneck(128, name=nm, drop_rate=rate, **variants[i], **kw))
+        # Stage 4
+        self.Bottleneck4_0 = mod.BottleneckUpsample(64, name="Bottleneck4_0", drop_rate=drop_rates[3], **kw)
+        self.Bottleneck4_1 = mod.Bottleneck(64, name="Bottleneck4_1", drop_rate=drop_rates[3], **kw)
+        self.Bottleneck4_2 = mod.Bottleneck(64, name="Bottleneck4_2", drop_rate=drop_rates[3], **kw)
+        # Stage 5
+        self.Bottleneck5_0 = mod.BottleneckUpsample(16, name="Bottleneck5_0", drop_rate=drop_rates[4], **kw)
+        self.Bottleneck5_1 = mod.Bottleneck(16, name="Bottleneck5_1", drop_rate=drop_rates[4], **kw)
+        # Final UpConv
+        self.Final = mod.Final(self.classes, kernel_initializer=kernel_initializer,
+                               kernel_regularizer=weight_regularization,
+                               regularization_scaling=regularization_scaling)
+
+        self._layer_names = (["Initial", "Bottleneck1_0"] + ["Bottleneck1_%d" % i for i in range(1, 5)]
+                             + ["Bottleneck2_0"] + ["Bottleneck2_%d" % i for i in range(1, 9)]
+                             + ["Bottleneck3_%d" % i for i in range(1, 9)]
+                             + ["Bottleneck4_0", "Bottleneck4_1", "Bottleneck4_2",
+                                "Bottleneck5_0", "Bottleneck5_1", "Final"])
+        for nm in self._layer_names:
+            getattr(self, nm)._owner = self
+        self._handle = None
+        self._c_in = None
+        self._pushed_versions = None
+        self._ws = None
+        self._endpoints = []
+        self.outputs = []
+
+    # ---- keras-like surface ----------------------------------------------------------------
+    @property
+    def layers(self):
+        return [getattr(self, nm) for nm in self._layer_names]
+
+    @property
+    def variables(self):
+        return [v for l in self.layers for v in l.variables]
+
+    weights = variables
+
+    def build(self, input_shape):
+        """Create all weights for an NHWC input shape (reference build :249-309 + lazy layer builds)."""
+        if self.built:
+            return
+        c = int(input_shape[-1])
+        self._c_in = c
+        for nm in self._layer_names:
+            layer = getattr(self, nm)
+            layer.build((None, None, None, c))
+            c = layer.output_shape(1, 8, 8)[-1]
+        self.built = True
+
+    @property
+    def endpoint_outputs(self):
+        """[[final, bottleneck5_1, bottleneck4_2, bottleneck3_8], ...] one entry per call
+        (reference :311-318).  The three intermediate tensors are views into the device workspace
+        of the most recent call and are overwritten by the next one."""
+        return list(self._endpoints)
+
+    # ---- device handle ---------------------------------------------------------------------
+    def _versions(self):
+        return tuple(v.version for v in self.variables)
+
+    def _sync_handle(self):
+        L = _lib.lib()
+        if self._handle is None:
+            h = ctypes.c_void_p()
+            _lib.check(L.ssal_enet_create(self._c_in, self.classes, ctypes.byref(h)))
+            self._handle = h
+        versions = self._versions()
+        if versions != self._pushed_versions:
+            for nm in self._layer_names:
+                for attr, var in getattr(self, nm).abi_tensors().items():
+                    arr = var.numpy()
+                    _lib.check(L.ssal_enet_set_tensor(
+                        self._handle, ("%s.%s" % (nm, attr)).encode(),
+                        arr.ctypes.data_as(ctypes.c_void_p), arr.size))
+            _lib.check(L.ssal_enet_commit(self._handle, _lib.stream_ptr()))
+            self._pushed_versions = versions
+        return self._handle
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                _lib.lib().ssal_enet_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    def _workspace(self, nbytes, device):
+        torch = _lib.require_gpu()
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        return self._ws
+
+    def _prepare(self, inputs, training):
+        if training:
+            raise NotImplementedError(
+                "training=True (spatial dropout + batch statistics) is outside the MI355X "
+                "scoring path; call with training=False")
+        x = _lib.as_device_f32(inputs)
+        if x.dim() != 4:
+            raise ValueError("inputs must be NHWC rank-4 (got shape %s)" % (tuple(x.shape),))
+        if not self.built:
+            self.build(tuple(x.shape))
+        if x.shape[-1] != self._c_in:
+            raise ValueError("model was built for %d input channels, got %d" % (self._c_in, x.shape[-1]))
+        return x
+
+    # ---- forward: ENet.call (reference :320-407) -------------------------------------------
+    def __call__(self, inputs, training):
+        if training:
+            raise NotImplementedError(
+                "training=True (spatial dropout + batch statistics) is outside the MI355X "
+                "scoring path; call with training=False")
+        torch = _lib.require_gpu()
+        x = self._prepare(inputs, training)
+        n, h, w, _ = x.shape
+        L = _lib.lib()
+        with torch.cuda.device(x.device):
+            handle = self._sync_handle()
+            nbytes = L.ssal_enet_workspace_bytes(handle, n, h, w)
+            if nbytes < 0:
+                raise ValueError("bad input dims %s" % (tuple(x.shape),))
+            ws = self._workspace(nbytes, x.device)
+            logits = torch.empty((n, h, w, self.classes), dtype=torch.float32, device=x.device)
+            _lib.check(L.ssal_enet_forward_nhwc(handle, _lib.dev_ptr(x), n, h, w, _lib.dev_ptr(logits),
+                                                _lib.dev_ptr(ws), ws.numel(), _lib.stream_ptr()))
+            self._record_endpoints(logits, ws, n, h, w)
+        self.outputs.append(logits)
+        return logits
+
+    call = __call__
+
+    def _record_endpoints(self, final, ws, n, h, w):
+        torch = _lib.require_gpu()
+        offs = (ctypes.c_int64 * 3)()
+        _lib.check(_lib.lib().ssal_enet_endpoint_offsets(self._handle, n, h, w, offs))
+        shapes = [(n, h // 2, w // 2, 16), (n, h // 4, w // 4, 64), (n, h // 8, w // 8, 128)]
+        views = []
+        for off, shp in zip(offs, shapes):
+            cnt = shp[0] * shp[1] * shp[2] * shp[3]
+            views.append(ws[off:off + 4 * cnt].view(torch.float32).view(shp))
+        self._endpoints.append([final] + views)
+        if len(self._endpoints) > 4:  # views alias one workspace: keep the list short
+            self._endpoints = self._endpoints[-4:]
+
+    # ---- fused pool scoring (active_learning.py:229-263) -----------------------------------
+    def score(self, inputs, measure="entropy", threshold=0.0, return_label=False,
+              return_mask=False, return_confidence=False, out=None):
+        """forward(training=False) + softmax + acquisition measure + float64 per-image mean.
+
+        Returns scores [N] float64 (device tensor); optionally a dict with the per-pixel
+        pseudo label (uint8), pseudo mask (uint8, conf >= threshold) and confidence (fp32)."""
+        if measure not in _lib.MEASURES:
+            raise NotImplementedError("Uncertainty function not implemented.")
+        torch = _lib.require_gpu()
+        x = self._prepare(inputs, False)
+        n, h, w, _ = x.shape
+        L = _lib.lib()
+        with torch.cuda.device(x.device):
+            handle = self._sync_handle()
+            nbytes = L.ssal_enet_workspace_bytes(handle, n, h, w)
+            if nbytes < 0:
+                raise ValueError("bad input dims %s" % (tuple(x.shape),))
+            ws = self._workspace(nbytes, x.device)
+            scores = out if out is not None else torch.empty((n,), dtype=torch.float64, device=x.device)
+            label = torch.empty((n, h, w), dtype=torch.uint8, device=x.device) if return_label else None
+            mask = torch.empty((n, h, w), dtype=torch.uint8, device=x.device) if return_mask else None
+            conf = torch.empty((n, h, w), dtype=torch.float32, device=x.device) if return_confidence else None
+            _lib.check(L.ssal_enet_score_nhwc(
+                handle, _lib.dev_ptr(x), n, h, w, _lib.MEASURES[measure], float(threshold),
+                _lib.dev_ptr(scores, torch.float64, "scores"), _lib.dev_ptr(label), _lib.dev_ptr(mask),
+                _lib.dev_ptr(conf), _lib.dev_ptr(ws), ws.numel(), _lib.stream_ptr()))
+        if return_label or return_mask or return_confidence:
+            return scores, {"label": label, "mask": mask, "confidence": conf}
+        return scores
+
+    # ---- single layer (Layer.__call__) -----------------------------------------------------
+    def _run_layer(self, layer, x, argmax_in, want_argmax):
+        torch = _lib.require_gpu()
+        if not self.built:
+            raise RuntimeError("build the model (call it once, or .build(input_shape)) before "
+                               "running single layers")
+        n, h, w, _ = x.shape
+        L = _lib.lib()
+        with torch.cuda.device(x.device):
+            handle = self._sync_handle()
+            name = layer.name.encode()
+            nbytes = L.ssal_enet_layer_workspace_bytes(handle, name, n, h, w)
+            ws = self._workspace(max(nbytes, 1024), x.device)
+            y = torch.empty(layer.output_shape(n, h, w), dtype=torch.float32, device=x.device)
+            amax_out = None
+            if want_argmax:
+                amax_out = torch.empty((n, h // 2, w // 2, x.shape[-1]), dtype=torch.int64, device=x.device)
+            amax_in = None
+            if argmax_in is not None:
+                amax_in = argmax_in if isinstance(argmax_in, torch.Tensor) else torch.as_tensor(argmax_in)
+                amax_in = amax_in.to(device=x.device, dtype=torch.int64).contiguous()
+                if tuple(amax_in.shape) != (n, h, w, layer.output_channels):
+                    raise ValueError("unpool_argmax must have shape %s (got %s)"
+                                     % ((n, h, w, layer.output_channels), tuple(amax_in.shape)))
+            _lib.check(L.ssal_enet_run_layer(handle, name, _lib.dev_ptr(x), n, h, w, _lib.dev_ptr(y),
+                                             _lib.dev_ptr(amax_out), _lib.dev_ptr(amax_in),
+                                             _lib.dev_ptr(ws), ws.numel(), _lib.stream_ptr()))
+        return (y, amax_out) if want_argmax else y

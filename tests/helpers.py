@@ -1,0 +1,32 @@
+"""shared test helpers (CPU side)"""
+import numpy as np
+
+import semanticsegmentationactivelearning_amd as ssal
+from semanticsegmentationactivelearning_amd import synthetic as syn
+
+
+def make_model(classes, c_in, seed=0):
+    net = ssal.ENet(classes)
+    net.build((None, None, None, c_in))
+    syn.randomize_enet(net, seed=seed)
+    return net, syn.enet_params_dict(net)
+
+
+def frames(ids, h, w, c, seed=0):
+    return syn.synth_frames_f32(ids, h, w, c, seed=seed)
+
+
+def report_diff(name, got, want, exact=True, atol=0.0):
+    """assert with a useful message: count / location / magnitude of mismatches"""
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape, "%s: shape %s != %s" % (name, got.shape, want.shape)
+    if exact:
+        bad = got != want
+    else:
+        bad = ~(np.abs(got.astype(np.float64) - want.astype(np.float64)) <= atol)
+    nbad = int(bad.sum())
+    if nbad:
+        first = tuple(int(i) for i in np.argwhere(bad)[0])
+        d = np.abs(got.astype(np.float64) - want.astype(np.float64))
+        raise AssertionError("%s: %d / %d elements differ (max |d| = %.3e, first at %s: got %r want %r)"
+                             % (name, nbad, got.size, float(np.nanmax(d)), first, got[first], want[first]))

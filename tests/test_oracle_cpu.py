@@ -1,0 +1,203 @@
+"""CPU tests of the parity oracle itself (no GPU): the C restatement against the committed golden
+vectors, against the independent torch-CPU restatement, against brute-force numpy loops written
+straight from the TF op definitions, and against the reference's own invariant
+(models/util/test_xops.py:6-21: max_pool -> unpool_2d -> max_pool is the identity)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from helpers import frames, report_diff
+from oracle import enet_oracle as orc
+from oracle import torch_restatement as tr
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _sha(arrs):
+    h = hashlib.sha256()
+    for a in arrs:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+# ---- brute force definitions (third, deliberately naive implementation) -----------------------------
+def naive_conv_same(x, w, stride, dil):
+    n, h, ww, cin = x.shape
+    kh, kw, _, co = w.shape
+    ho, wo = -(-h // stride), -(-ww // stride)
+    th = max((ho - 1) * stride + (kh - 1) * dil + 1 - h, 0)
+    tw = max((wo - 1) * stride + (kw - 1) * dil + 1 - ww, 0)
+    xp = np.zeros((n, h + th, ww + tw, cin), np.float64)
+    xp[:, th // 2: th // 2 + h, tw // 2: tw // 2 + ww] = x
+    y = np.zeros((n, ho, wo, co), np.float64)
+    for oy in range(ho):
+        for ox in range(wo):
+            for a in range(kh):
+                for b in range(kw):
+                    y[:, oy, ox] += xp[:, oy * stride + a * dil, ox * stride + b * dil] @ w[a, b].astype(np.float64)
+    return y
+
+
+def naive_convT(x, w):
+    """out[2i+kh, 2j+kw, o] += in[i,j,c] * W[kh,kw,o,c]; crop to 2H x 2W"""
+    n, h, ww, cin = x.shape
+    co = w.shape[2]
+    y = np.zeros((n, 2 * h + 1, 2 * ww + 1, co), np.float64)
+    for i in range(h):
+        for j in range(ww):
+            for a in range(3):
+                for b in range(3):
+                    y[:, 2 * i + a, 2 * j + b] += x[:, i, j].astype(np.float64) @ w[a, b].astype(np.float64).T
+    return y[:, : 2 * h, : 2 * ww]
+
+
+@pytest.mark.parametrize("kh,kw,stride,dil,h,w,cin,cout", [
+    (3, 3, 1, 1, 6, 7, 4, 5), (3, 3, 2, 1, 8, 10, 3, 13), (3, 3, 2, 1, 7, 9, 3, 4), (2, 2, 2, 1, 8, 6, 4, 8),
+    (3, 3, 1, 2, 9, 9, 4, 4), (3, 3, 1, 16, 8, 20, 4, 4), (5, 1, 1, 1, 7, 6, 4, 4), (1, 5, 1, 1, 6, 9, 4, 4),
+    (1, 1, 1, 1, 5, 5, 8, 16),
+])
+def test_conv2d_same_matches_definition(kh, kw, stride, dil, h, w, cin, cout):
+    rng = np.random.default_rng(1)
+    x = rng.normal(size=(2, h, w, cin)).astype(np.float32)
+    k = rng.normal(size=(kh, kw, cin, cout)).astype(np.float32)
+    got = orc.conv2d_same(x, k, stride, dil)
+    want = naive_conv_same(x, k, stride, dil)
+    assert np.abs(got - want).max() < 1e-4
+    gb = tr.conv2d_same(tr._t(x).permute(0, 3, 1, 2), k, stride, dil).permute(0, 2, 3, 1).numpy()
+    assert np.abs(gb - want).max() < 1e-4
+
+
+@pytest.mark.parametrize("h,w,cin,cout", [(4, 5, 4, 3), (3, 3, 8, 19), (1, 1, 4, 4)])
+def test_conv2d_transpose_matches_definition(h, w, cin, cout):
+    rng = np.random.default_rng(2)
+    x = rng.normal(size=(2, h, w, cin)).astype(np.float32)
+    k = rng.normal(size=(3, 3, cout, cin)).astype(np.float32)
+    got = orc.conv2d_transpose_3x3_s2(x, k)
+    want = naive_convT(x, k)
+    assert got.shape == (2, 2 * h, 2 * w, cout)
+    assert np.abs(got - want).max() < 1e-4
+    gb = tr.conv2d_transpose_3x3_s2(tr._t(x).permute(0, 3, 1, 2), k).permute(0, 2, 3, 1).numpy()
+    assert np.abs(gb - want).max() < 1e-4
+
+
+def test_pool_unpool_pool_identity():
+    """the reference's only test (models/util/test_xops.py:6-21), seeded; both index conventions"""
+    rng = np.random.default_rng(3)
+    x = rng.uniform(size=(4, 32, 32, 3)).astype(np.float32)
+    for with_batch in (False, True):
+        mp, am = orc.maxpool2x2_argmax(x, include_batch=with_batch)
+        up = orc.unpool2d(mp, am, idx_has_batch=with_batch)
+        mp2, _ = orc.maxpool2x2_argmax(up)
+        assert np.sum(np.abs(mp - mp2)) == 0.0
+        assert np.count_nonzero(up) <= mp.size
+
+
+def test_argmax_index_convention_and_ties():
+    x = np.zeros((2, 4, 4, 2), np.float32)
+    x[1, 2, 3, 1] = 5.0  # window (1,1) of image 1, position dy=0, dx=1
+    mp, am = orc.maxpool2x2_argmax(x)
+    assert am[1, 1, 1, 1] == (2 * 4 + 3) * 2 + 1
+    # all-equal window: the first element in (y, x) order wins (strict '>')
+    assert am[0, 0, 0, 0] == 0 and am[0, 1, 0, 1] == (2 * 4 + 0) * 2 + 1
+    _, amb = orc.maxpool2x2_argmax(x, include_batch=True)
+    assert amb[1, 1, 1, 1] == am[1, 1, 1, 1] + 4 * 4 * 2
+    # the torch restatement uses the same convention
+    _, amt = tr.max_pool_with_argmax(tr._t(x).permute(0, 3, 1, 2))
+    assert (amt.permute(0, 2, 3, 1).numpy() == am).all()
+
+
+def test_prelu_is_reference_formula():
+    rng = np.random.default_rng(4)
+    x = rng.normal(size=(1, 3, 3, 8)).astype(np.float32)
+    a = rng.uniform(-0.5, 0.5, size=8).astype(np.float32)
+    want = np.maximum(x, 0) - a * np.maximum(-x, 0)  # extra_ops.py:21-26
+    got = orc.affine_prelu(x, None, None, a)
+    assert (got == want).all()
+
+
+def test_bn_fold_close_to_tf_formula():
+    rng = np.random.default_rng(5)
+    c = 16
+    m, v = rng.normal(0, 0.1, c).astype(np.float32), rng.uniform(0.5, 1.5, c).astype(np.float32)
+    g, b = rng.uniform(0.8, 1.2, c).astype(np.float32), rng.normal(0, 0.1, c).astype(np.float32)
+    x = rng.normal(size=(1, 4, 4, c)).astype(np.float32)
+    s, t = orc.bn_fold(m, v, g, b)
+    got = orc.affine_prelu(x, s, t, None)
+    want = (x.astype(np.float64) - m) / np.sqrt(v.astype(np.float64) + 1e-3) * g + b
+    assert np.abs(got - want).max() < 1e-5
+
+
+@pytest.mark.parametrize("measure", ["entropy", "margin", "confidence"])
+@pytest.mark.parametrize("k", [2, 6, 19])
+def test_score_matches_literal_numpy(measure, k):
+    """active_learning.py:239-263 written out with numpy float32"""
+    rng = np.random.default_rng(6)
+    lg = (rng.normal(size=(2, 5, 7, k)) * 3).astype(np.float32)
+    mean, conf, label = orc.score_logits(lg, measure)
+    e = np.exp(lg - lg.max(-1, keepdims=True))
+    p = (e / e.sum(-1, keepdims=True)).astype(np.float32)
+    if measure == "entropy":
+        ent = -(p * np.log(p + np.finfo(np.float32).tiny)).sum(-1)
+        want = 1.0 - ent / np.log(np.float32(k))
+    elif measure == "margin":
+        srt = np.sort(p, -1)
+        want = srt[..., -1] - srt[..., -2]
+    else:
+        want = p.max(-1)
+    assert np.abs(conf - want).max() < 1e-5
+    assert (label == lg.argmax(-1)).all()
+    assert np.abs(mean - want.astype(np.float64).mean((1, 2))).max() < 1e-6
+    with pytest.raises(NotImplementedError):
+        orc.score_logits(lg, "bald")
+
+
+def test_oracle_vs_torch_restatement_small(enet_c3k19):
+    _, P = enet_c3k19
+    x = frames([5, 6], 32, 64, 3)
+    ea, eb = {}, {}
+    la = orc.enet_forward(P, x, ea)
+    lb = tr.enet_forward(P, x, eb)
+    assert (ea["argmax1"] == eb["argmax1"]).all() and (ea["argmax2"] == eb["argmax2"]).all()
+    for name in ea:
+        if not name.startswith("argmax"):
+            assert np.abs(ea[name] - eb[name]).max() < 1e-4, name
+    assert np.abs(la - lb).max() < 1e-4
+
+
+@pytest.mark.parametrize("case,fixture", [("enet_c3k19_64x128", "enet_c3k19"), ("enet_c4k6_64x64", "enet_c4k6")])
+def test_oracle_reproduces_golden(case, fixture, request):
+    """the committed fixtures (tests/golden/make_golden.py) are reproduced bit-for-bit"""
+    _, P = request.getfixturevalue(fixture)
+    g = np.load(os.path.join(GOLDEN, case + ".npz"))
+    assert _sha([P[k] for k in sorted(P)]) == str(g["weights_sha256"]), "synthetic weight recipe drifted"
+    h, w = g["logits"].shape[1:3]
+    x = frames(list(g["frame_ids"]), h, w, P["Initial.kernel"].shape[2])
+    assert _sha([x]) == str(g["frames_sha256"]), "synthetic frame recipe drifted"
+    ep = {}
+    logits = orc.enet_forward(P, x, ep)
+    report_diff("logits", logits, g["logits"])
+    report_diff("argmax1", ep["argmax1"], g["argmax1"])
+    report_diff("argmax2", ep["argmax2"], g["argmax2"])
+    report_diff("label", logits.argmax(-1).astype(np.uint8), g["label"])
+    for m in ("entropy", "margin", "confidence"):
+        mean, conf, _ = orc.score_logits(logits, m)
+        assert np.abs(mean - g["mean_" + m]).max() < 1e-12
+        report_diff("conf_" + m, conf[0], g["conf_" + m], exact=False, atol=1e-6)
+
+
+def test_golden_scores_separate():
+    """fixtures must assert a real decision margin: per-image scores differ by >> 1e-4"""
+    g = np.load(os.path.join(GOLDEN, "enet_c3k19_64x128.npz"))
+    for m in ("entropy", "margin", "confidence"):
+        s = np.sort(g["mean_" + m].astype(np.float32))
+        assert np.diff(s).min() > 1e-3, (m, s)
+
+
+def test_rank_lowest_matches_reference_tail():
+    scores = np.array([0.9, 0.1, 0.5, 0.3, 0.7, 0.2], np.float64)
+    unl = np.array([0, 1, 3, 4, 5])
+    ids, uc = orc.rank_lowest(scores, unl, 2)
+    assert set(ids.tolist()) == {1, 5}
+    assert uc.dtype == np.float32 and len(uc) == 5

@@ -135,6 +135,12 @@ int ssal_resize_bilinear(const float *x_dev, int n, int h, int w, int c, int oh,
 int ssal_synth_frames_nhwc(uint64_t seed, int64_t first_frame, int count, int h, int w, int c,
                            float *out_dev, void *stream);
 
+/* Measurement aid (no reference counterpart): when enabled, every kernel launch is bracketed by
+ * HIP events on its own stream; ssal_profile_collect() returns per-kernel launch counts, total
+ * milliseconds and ALGORITHMIC flops / bytes as a JSON object.  Single host thread only. */
+int ssal_profile_enable(int on);
+int ssal_profile_collect(char *json_out, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

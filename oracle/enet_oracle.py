@@ -26,10 +26,16 @@ _f32p = ctypes.POINTER(ctypes.c_float)
 
 
 def build(force=False):
+    """gcc-compile the C restatement (content-stamped: mtimes do not survive a snapshot copy)"""
+    import hashlib
     src = os.path.join(_HERE, "enet_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "libenet_oracle.so"],
-                              stdout=subprocess.DEVNULL)
+    digest = hashlib.sha256(open(src, "rb").read() + open(os.path.join(_HERE, "Makefile"), "rb").read()).hexdigest()
+    stamp = _SO + ".stamp"
+    fresh = os.path.exists(_SO) and os.path.exists(stamp) and open(stamp).read().strip() == digest
+    if force or not fresh:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libenet_oracle.so"], stdout=subprocess.DEVNULL)
+        with open(stamp, "w") as f:
+            f.write(digest)
     return _SO
 
 
@@ -37,6 +43,9 @@ def _lib():
     global _LIB
     if _LIB is None:
         build()
+        if "OMP_NUM_THREADS" not in os.environ:  # size the OpenMP pool to the box's real CPU share
+            from semanticsegmentationactivelearning_amd._lib import usable_cores
+            os.environ["OMP_NUM_THREADS"] = str(usable_cores(cap=32))
         _LIB = ctypes.CDLL(_SO)
     return _LIB
 

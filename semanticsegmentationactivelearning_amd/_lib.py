@@ -44,6 +44,8 @@ PROTOTYPES = {
     "ssal_conv2d_transpose_3x3_s2": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "ssal_resize_bilinear": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ssal_synth_frames_nhwc": (_i, [_c.c_uint64, _i64, _i, _i, _i, _i, _vp, _vp]),
+    "ssal_profile_enable": (_i, [_i]),
+    "ssal_profile_collect": (_i, [_c.c_char_p, _i64]),
 }
 
 _LIB = None
@@ -58,6 +60,10 @@ def lib():
                 "libssal_hip.so is missing (%s). Build it with "
                 "`python -c 'import __graft_entry__ as g; g.build()'`. "
                 "The MI355X HIP path has no CPU fallback." % LIB_PATH)
+        # torch ships its own libamdhip64.so.7 / libhsa-runtime64: it must be mapped BEFORE our
+        # library so that both share ONE HIP runtime (loading ours first would bind torch to the
+        # system runtime + its bundled HSA and no device would be found).
+        _torch()
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
@@ -84,6 +90,35 @@ def check(status):
 def _torch():
     import torch
     return torch
+
+
+def usable_cores(cap=None):
+    """CPU threads this process may really use: min(affinity, cgroup quota[, cap]).  A GPU box
+    exposes every host core in the affinity mask but grants a 1-GPU job only a ~16-CPU share;
+    sizing thread pools to the mask would oversubscribe it badly."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota> <period>" or "max <period>"
+            q, p = f.read().split()[:2]
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    env = os.environ.get("SSAL_CPU_THREADS")
+    if env:
+        n = min(n, max(1, int(env)))
+    if cap:
+        n = min(n, cap)
+    return max(1, n)
 
 
 def require_gpu():
@@ -125,3 +160,15 @@ def as_device_f32(x, device=None):
     if not x.is_cuda:
         x = x.cuda(device) if device is not None else x.cuda()
     return x.contiguous()
+
+
+def profile_enable(on=True):
+    check(lib().ssal_profile_enable(1 if on else 0))
+
+
+def profile_collect():
+    """-> {kernel: {"launches", "ms", "flops", "bytes"}} for every launch since the last collect"""
+    import json
+    buf = ctypes.create_string_buffer(1 << 16)
+    check(lib().ssal_profile_collect(buf, len(buf)))
+    return json.loads(buf.value.decode())

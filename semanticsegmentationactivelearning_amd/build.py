@@ -18,13 +18,25 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-def needs_build():
-    if not os.path.exists(OUT):
-        return True
-    t = os.path.getmtime(OUT)
-    deps = sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+STAMP = OUT + ".stamp"
+
+
+def _digest():
+    """content hash of every input of the build (mtimes do not survive a repo snapshot copy)"""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    deps = sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
     deps.append(os.path.join(HERE, "..", "include", "ssal_enet.h"))
-    return any(os.path.getmtime(d) > t for d in deps)
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        h.update(open(d, "rb").read())
+    return h.hexdigest()
+
+
+def needs_build():
+    if not os.path.exists(OUT) or not os.path.exists(STAMP):
+        return True
+    return open(STAMP).read().strip() != _digest()
 
 
 def build(force=False, verbose=True):
@@ -36,6 +48,8 @@ def build(force=False, verbose=True):
         print("[ssal build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     os.replace(OUT + ".tmp", OUT)
+    with open(STAMP, "w") as f:
+        f.write(_digest())
     return OUT
 
 

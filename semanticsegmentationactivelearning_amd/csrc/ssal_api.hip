@@ -2,6 +2,7 @@
 // sequencing.  Host C++ only; no torch types.  gfx950 (MI355X) only.
 #include "../../include/ssal_enet.h"
 #include "ssal_internal.h"
+#include "ssal_prof.h"
 
 #include <math.h>
 #include <stdarg.h>
@@ -933,5 +934,85 @@ SSAL_API int ssal_synth_frames_nhwc(uint64_t seed, int64_t first_frame, int coun
     if (count <= 0 || h <= 0 || w <= 0 || c <= 0 || h % 8 || w % 8)
         return fail(SSAL_EINVAL, "bad dims count=%d h=%d w=%d c=%d (H, W must be divisible by 8)", count, h, w, c);
     HIP_TRY(launch_synth_frames(seed, first_frame, count, h, w, c, out_dev, (hipStream_t)stream));
+    return SSAL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-kernel timing (HIP events on the launch stream); see ssal_prof.h
+// ------------------------------------------------------------------------------------------------
+namespace ssal {
+namespace {
+struct ProfRec {
+    const char *name;
+    hipEvent_t a, b;
+    double flops, bytes;
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_recs;
+std::vector<hipEvent_t> g_event_pool;
+
+hipEvent_t get_event()
+{
+    if (!g_event_pool.empty()) {
+        hipEvent_t e = g_event_pool.back();
+        g_event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+
+bool prof_enabled() { return g_prof_on; }
+
+void prof_begin(const char *kernel, double flops, double bytes, hipStream_t s)
+{
+    ProfRec r{kernel, get_event(), get_event(), flops, bytes};
+    (void)hipEventRecord(r.a, s);
+    g_recs.push_back(r);
+}
+
+void prof_end(hipStream_t s)
+{
+    if (!g_recs.empty()) (void)hipEventRecord(g_recs.back().b, s);
+}
+}  // namespace ssal
+
+SSAL_API int ssal_profile_enable(int on)
+{
+    ssal::g_prof_on = on != 0;
+    return SSAL_OK;
+}
+
+// Waits for every recorded launch, aggregates per kernel name and writes a JSON object
+// {"kernel": {"launches": n, "ms": total, "flops": total, "bytes": total}, ...}; clears the records.
+SSAL_API int ssal_profile_collect(char *json_out, int64_t cap)
+{
+    if (!json_out || cap < 64) return fail(SSAL_EINVAL, "json_out too small");
+    struct Agg { long n = 0; double ms = 0, flops = 0, bytes = 0; };
+    std::map<std::string, Agg> agg;
+    for (auto &r : ssal::g_recs) {
+        HIP_TRY(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+        Agg &g = agg[r.name];
+        g.n += 1; g.ms += ms; g.flops += r.flops; g.bytes += r.bytes;
+        ssal::g_event_pool.push_back(r.a);
+        ssal::g_event_pool.push_back(r.b);
+    }
+    ssal::g_recs.clear();
+    std::string js = "{";
+    bool first = true;
+    for (auto &kv : agg) {
+        char buf[256];
+        snprintf(buf, sizeof(buf), "%s\"%s\": {\"launches\": %ld, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
+                 first ? "" : ", ", kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.flops, kv.second.bytes);
+        js += buf;
+        first = false;
+    }
+    js += "}";
+    if ((int64_t)js.size() + 1 > cap) return fail(SSAL_ENOMEM, "json_out too small (%zu needed)", js.size() + 1);
+    memcpy(json_out, js.c_str(), js.size() + 1);
     return SSAL_OK;
 }

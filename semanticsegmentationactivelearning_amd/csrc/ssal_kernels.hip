@@ -9,6 +9,7 @@
 //
 // Reference semantics restated per kernel (file:line relative to the reference repository).
 #include "ssal_internal.h"
+#include "ssal_prof.h"
 #include <float.h>
 
 namespace ssal {
@@ -89,6 +90,7 @@ hipError_t launch_initial(const float *x, int N, int H, int W, int Cin, const fl
 {
     const long total = (long)N * (H / 2) * (W / 2);
     const int grid = cdiv(total, 256);
+    ProfScope prof("k_initial", 2.0 * total * 9 * Cin * (16 - Cin), 4.0 * ((double)N * H * W * Cin + total * 16.0), s);
     if (Cin == 3)
         hipLaunchKernelGGL(k_initial<3>, dim3(grid), dim3(256), 0, s, x, w, scale, shift, alpha, y, N, H, W);
     else if (Cin == 4)
@@ -213,6 +215,12 @@ hipError_t launch_conv(const ConvArgs &a, hipStream_t s)
     const int gpb = 256 / a.Cout;
     const long grid = (ngroups + gpb - 1) / gpb;
     if (grid <= 0 || grid > 0x7fffffffL) return hipErrorInvalidValue;
+    const double opix = (double)a.N * a.Ho * a.Wo;
+    double bytes = 4.0 * ((double)a.N * a.H * a.W * a.Cin + opix * a.Cout + (double)a.KH * a.KW * a.Cin * a.Cout);
+    if (a.res_mode == RES_ADD) bytes += 4.0 * opix * a.Cout;
+    if (a.res_mode == RES_POOL) bytes += 4.0 * opix * 4 * a.res_C + opix * a.res_C;
+    if (a.res_mode == RES_UNPOOL) bytes += (4.0 + 1.0) * opix / 4 * a.Cout;
+    ProfScope prof("k_conv", 2.0 * opix * a.Cout * a.KH * a.KW * a.Cin, bytes, s);
     hipLaunchKernelGGL(k_conv<PX>, dim3((unsigned)grid), dim3(256), 0, s, a);
     return hipGetLastError();
 }
@@ -276,6 +284,8 @@ hipError_t launch_convT(const float *x, int N, int H, int W, int Cin, const floa
     const int ppb = 256 / Cout;
     const long grid = (npix + ppb - 1) / ppb;
     if (grid <= 0 || grid > 0x7fffffffL) return hipErrorInvalidValue;
+    ProfScope prof("k_convT", 2.0 * (double)N * H * W * 9 * Cin * Cout,
+                   4.0 * ((double)N * H * W * Cin + (double)npix * Cout + 9.0 * Cin * Cout), s);
     hipLaunchKernelGGL(k_convT, dim3((unsigned)grid), dim3(256), 0, s, x, N, H, W, Cin, wT, Cout,
                        scale, shift, alpha, y);
     return hipGetLastError();
@@ -441,6 +451,9 @@ hipError_t launch_final_score(const float *x, int N, int H, int W, const float *
                               uint8_t *label, uint8_t *mask, float *conf, hipStream_t s)
 {
     dim3 grid(final_score_blocks(H, W), N), block(256);
+    ProfScope prof("k_final_score", 2.0 * (double)N * H * W * 9 * 16 * K,
+                   4.0 * ((double)N * H * W * 16 + (logits ? (double)N * 4 * H * W * K : 0.0)) +
+                       (double)N * 4 * H * W * ((label ? 1 : 0) + (mask ? 1 : 0) + (conf ? 4 : 0)), s);
 #define SSAL_FS(KK)                                                                               \
     case KK:                                                                                      \
         hipLaunchKernelGGL(k_final_score<KK>, grid, block, 0, s, x, N, H, W, wF, logits, measure, \
@@ -497,10 +510,11 @@ __global__ __launch_bounds__(256) void k_score_logits(const float *__restrict__ 
     const int n = blockIdx.y;
     const long p0 = (long)blockIdx.x * 256;
     const int npx = (int)((HW - p0) < 256 ? (HW - p0) : 256);
-    const float *src = logits + ((long)n * HW + p0) * K;  // 256*K*4 B block offset: 16-B aligned
+    const float *src = logits + ((long)n * HW + p0) * K;
     const int nflt = npx * K;
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(src) & 15u) == 0;  // block-uniform
     for (int f = threadIdx.x * 4; f < nflt; f += 1024) {
-        if (f + 3 < nflt) {
+        if (vec_ok && f + 3 < nflt) {
             const float4 t = *reinterpret_cast<const float4 *>(src + f);
             const float tv[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
@@ -509,7 +523,7 @@ __global__ __launch_bounds__(256) void k_score_logits(const float *__restrict__ 
                 tile[(e / K) * KP + (e % K)] = tv[q];
             }
         } else {
-            for (int e = f; e < nflt; ++e) tile[(e / K) * KP + (e % K)] = src[e];
+            for (int e = f; e < nflt && e < f + 4; ++e) tile[(e / K) * KP + (e % K)] = src[e];
         }
     }
     __syncthreads();
@@ -538,6 +552,8 @@ hipError_t launch_score_logits(const float *logits, int N, int H, int W, int K, 
 {
     dim3 grid(score_blocks(H, W), N), block(256);
     const long HW = (long)H * W;
+    ProfScope prof("k_score_logits", (double)N * HW * K * 6.0,
+                   (double)N * HW * (4.0 * K + (label ? 1 : 0) + (mask ? 1 : 0) + (conf ? 4 : 0)), s);
 #define SSAL_SL(KK)                                                                              \
     case KK:                                                                                     \
         hipLaunchKernelGGL(k_score_logits<KK>, grid, block, 0, s, logits, N, HW, measure,        \

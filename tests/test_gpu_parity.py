@@ -1,0 +1,360 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical seeded
+inputs.  Integer / index results (pool argmax, class argmax, top-k ids) must be bit-exact; fp32
+activations and logits are compared bit-for-bit against the C restatement (same accumulation
+order) AND within 1e-4 of the independent torch-CPU restatement; softmax / entropy / margin within
+1e-4 (north_star tolerance, written at each assert).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import semanticsegmentationactivelearning_amd as ssal
+from helpers import frames, report_diff
+from oracle import enet_oracle as orc
+from oracle import torch_restatement as tr
+from semanticsegmentationactivelearning_amd import _lib, active_learning as al, synthetic as syn
+from semanticsegmentationactivelearning_amd.models.util import extra_ops as xops
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-4  # north_star: softmax/entropy within 1e-4 fp32
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    torch.cuda.set_device(0)
+    _lib.lib()  # the HIP extension must be the thing that runs
+    yield
+    torch.cuda.synchronize()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# ---- synthetic frames: device generator == host twin ---------------------------------------------
+@pytest.mark.parametrize("h,w,c,first,count", [(64, 128, 3, 0, 3), (32, 32, 4, 2970, 2), (8, 8, 1, 5, 1)])
+def test_synth_frames_device_equals_host(h, w, c, first, count):
+    got = syn.synth_frames_device(first, count, h, w, c).cpu().numpy()
+    want = frames(range(first, first + count), h, w, c)
+    report_diff("frames", got, want)
+
+
+# ---- stand-alone operators -----------------------------------------------------------------------
+@pytest.mark.parametrize("kh,kw,stride,dil,h,w,cin,cout", [
+    (1, 1, 1, 1, 16, 24, 64, 16), (1, 1, 1, 1, 9, 7, 16, 64), (1, 1, 1, 1, 8, 8, 32, 128), (1, 1, 1, 1, 8, 8, 128, 32),
+    (3, 3, 1, 1, 16, 20, 16, 16), (3, 3, 1, 2, 16, 20, 32, 32), (3, 3, 1, 4, 9, 11, 32, 32),
+    (3, 3, 1, 8, 16, 24, 32, 32), (3, 3, 1, 16, 16, 40, 32, 32), (5, 1, 1, 1, 12, 10, 32, 32),
+    (1, 5, 1, 1, 12, 10, 32, 32), (2, 2, 2, 1, 16, 24, 16, 8), (2, 2, 2, 1, 8, 8, 64, 32),
+    (3, 3, 1, 1, 10, 6, 4, 4), (3, 3, 1, 1, 6, 5, 8, 8), (3, 3, 2, 1, 9, 7, 4, 8),
+])
+def test_conv2d_same_bit_exact(kh, kw, stride, dil, h, w, cin, cout):
+    rng = np.random.default_rng(10)
+    x = rng.normal(size=(2, h, w, cin)).astype(np.float32)
+    k = (rng.normal(size=(kh, kw, cin, cout)) * 0.2).astype(np.float32)
+    want = orc.conv2d_same(x, k, stride, dil)
+    y = torch.empty(want.shape, dtype=torch.float32, device="cuda")
+    xd, kd = dev(x), dev(k)  # keep the device tensors alive across the call
+    _lib.check(_lib.lib().ssal_conv2d_same(_lib.dev_ptr(xd), 2, h, w, cin, _lib.dev_ptr(kd), kh, kw, cout,
+                                           stride, dil, _lib.dev_ptr(y), _lib.stream_ptr()))
+    report_diff("conv2d", y.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("h,w,cin,cout", [(8, 12, 32, 16), (5, 7, 16, 8), (4, 4, 16, 16), (1, 1, 4, 4)])
+def test_conv2d_transpose_bit_exact(h, w, cin, cout):
+    rng = np.random.default_rng(11)
+    x = rng.normal(size=(2, h, w, cin)).astype(np.float32)
+    k = (rng.normal(size=(3, 3, cout, cin)) * 0.2).astype(np.float32)
+    want = orc.conv2d_transpose_3x3_s2(x, k)
+    y = torch.empty(want.shape, dtype=torch.float32, device="cuda")
+    xd, kd = dev(x), dev(k)
+    _lib.check(_lib.lib().ssal_conv2d_transpose_3x3_s2(_lib.dev_ptr(xd), 2, h, w, cin, _lib.dev_ptr(kd),
+                                                       cout, _lib.dev_ptr(y), _lib.stream_ptr()))
+    report_diff("conv2d_transpose", y.cpu().numpy(), want)
+
+
+def test_conv_argument_errors():
+    x = torch.zeros((1, 4, 4, 3), device="cuda")
+    k = torch.zeros((3, 3, 3, 8), device="cuda")
+    y = torch.zeros((1, 4, 4, 8), device="cuda")
+    with pytest.raises(ValueError):
+        _lib.check(_lib.lib().ssal_conv2d_same(_lib.dev_ptr(x), 1, 4, 4, 3, _lib.dev_ptr(k), 3, 3, 8, 1, 1,
+                                               _lib.dev_ptr(y), _lib.stream_ptr()))
+
+
+@pytest.mark.parametrize("include_batch", [False, True])
+def test_max_pool_with_argmax_and_unpool(include_batch):
+    rng = np.random.default_rng(12)
+    x = rng.uniform(size=(3, 16, 24, 5)).astype(np.float32)
+    x[0, :2, :2, 0] = 0.5  # a tie: first element of the window must win
+    want_y, want_i = orc.maxpool2x2_argmax(x, include_batch=include_batch)
+    y, idx = xops.max_pool_with_argmax(dev(x), include_batch_in_index=include_batch)
+    report_diff("pool", y.cpu().numpy(), want_y)
+    report_diff("argmax", idx.cpu().numpy(), want_i)
+    up = xops.unpool_2d(y, idx, idx_has_batch=include_batch)
+    report_diff("unpool", up.cpu().numpy(), orc.unpool2d(want_y, want_i, idx_has_batch=include_batch))
+    # reference invariant (models/util/test_xops.py:6-21): pool(unpool(pool(x))) == pool(x), error exactly 0
+    y2, _ = xops.max_pool_with_argmax(up)
+    assert float((y - y2).abs().sum()) == 0.0
+
+
+def test_prelu_and_batch_norm_ops():
+    rng = np.random.default_rng(13)
+    x = rng.normal(size=(2, 6, 5, 16)).astype(np.float32)
+    a = rng.uniform(-0.5, 0.5, 16).astype(np.float32)
+    report_diff("prelu", xops.prelu(dev(x), dev(a)).cpu().numpy(), orc.affine_prelu(x, None, None, a))
+    m, v = rng.normal(0, 0.1, 16).astype(np.float32), rng.uniform(0.5, 1.5, 16).astype(np.float32)
+    g, b = rng.uniform(0.8, 1.2, 16).astype(np.float32), rng.normal(0, 0.1, 16).astype(np.float32)
+    s, t = orc.bn_fold(m, v, g, b)
+    out, um, uv = xops.batch_norm(dev(x), dev(m), dev(v), dev(g), dev(b), training=False)
+    assert um is None and uv is None
+    report_diff("batch_norm", out.cpu().numpy(), orc.affine_prelu(x, s, t, None))
+    with pytest.raises(NotImplementedError):
+        xops.batch_norm(dev(x), dev(m), dev(v), dev(g), dev(b), training=True)
+    with pytest.raises(NotImplementedError):
+        xops.spatial_dropout(dev(x), 0.1)
+
+
+def test_resize_bilinear_tf113_legacy_mapping():
+    """tf.image.resize_bilinear defaults in TF 1.13: align_corners=False, src = dst * in/out"""
+    rng = np.random.default_rng(14)
+    x = rng.normal(size=(2, 5, 7, 3)).astype(np.float32)
+    oh, ow = 13, 10
+    y = torch.empty((2, oh, ow, 3), dtype=torch.float32, device="cuda")
+    xd = dev(x)
+    _lib.check(_lib.lib().ssal_resize_bilinear(_lib.dev_ptr(xd), 2, 5, 7, 3, oh, ow, _lib.dev_ptr(y), _lib.stream_ptr()))
+    hs, ws = np.float32(5) / np.float32(oh), np.float32(7) / np.float32(ow)
+    want = np.empty((2, oh, ow, 3), np.float32)
+    for oy in range(oh):
+        fy = np.float32(oy) * hs
+        y0 = int(np.floor(fy)); y1 = min(y0 + 1, 4); ly = np.float32(fy - np.float32(y0))
+        for ox in range(ow):
+            fx = np.float32(ox) * ws
+            x0 = int(np.floor(fx)); x1 = min(x0 + 1, 6); lx = np.float32(fx - np.float32(x0))
+            top = x[:, y0, x0] + (x[:, y0, x1] - x[:, y0, x0]) * lx
+            bot = x[:, y1, x0] + (x[:, y1, x1] - x[:, y1, x0]) * lx
+            want[:, oy, ox] = top + (bot - top) * ly
+    report_diff("resize_bilinear", y.cpu().numpy(), want, exact=False, atol=1e-6)
+
+
+# ---- score kernel on materialised logits ---------------------------------------------------------
+@pytest.mark.parametrize("measure", ["entropy", "margin", "confidence"])
+@pytest.mark.parametrize("n,h,w,k", [(2, 16, 32, 19), (1, 5, 7, 6), (3, 24, 40, 2), (1, 8, 8, 32), (2, 3, 3, 19)])
+def test_score_logits_kernel(measure, n, h, w, k):
+    rng = np.random.default_rng(15)
+    lg = (rng.normal(size=(n, h, w, k)) * 4).astype(np.float32)
+    lg[0, 0, 0, :] = 1.25  # all classes tie: label 0, margin 0, entropy conf 0
+    want_mean, want_conf, want_label = orc.score_logits(lg, measure)
+    thr = float(np.median(want_conf))
+    scores, extra = al.score_logits(dev(lg), measure, threshold=thr, return_label=True, return_mask=True,
+                                    return_confidence=True)
+    report_diff("label (bit-exact argmax)", extra["label"].cpu().numpy(), want_label)
+    conf = extra["confidence"].cpu().numpy()
+    report_diff("confidence", conf, want_conf, exact=False, atol=TOL)  # 1e-4 tolerance (north_star)
+    assert np.abs(conf - want_conf).max() < 5e-6  # what the kernel actually achieves
+    report_diff("mean", scores.cpu().numpy(), want_mean, exact=False, atol=1e-6)
+    mask = extra["mask"].cpu().numpy()
+    sure = np.abs(want_conf - thr) > 1e-5
+    assert ((mask == (want_conf >= thr))[sure]).all()
+    assert (mask == (conf >= np.float32(thr))).all()  # active_learning.py:265-269 on the kernel's own conf
+
+
+def test_score_logits_errors():
+    lg = torch.zeros((1, 4, 4, 19), device="cuda")
+    with pytest.raises(NotImplementedError):
+        al.score_logits(lg, "bald")
+    with pytest.raises(ValueError):
+        al.score_logits(torch.zeros((1, 4, 4, 40), device="cuda"), "entropy")
+
+
+# ---- single layers through ssal_enet_run_layer ---------------------------------------------------
+def _layer_cases():
+    return [("Initial", 16, 24), ("Bottleneck1_0", 16, 24), ("Bottleneck1_1", 12, 20), ("Bottleneck2_0", 8, 12),
+            ("Bottleneck2_1", 9, 11), ("Bottleneck2_2", 9, 11), ("Bottleneck2_3", 9, 11), ("Bottleneck2_4", 12, 9),
+            ("Bottleneck2_6", 18, 20), ("Bottleneck3_7", 6, 13), ("Bottleneck3_8", 34, 36), ("Bottleneck4_0", 6, 8),
+            ("Bottleneck4_2", 8, 8), ("Bottleneck5_0", 6, 10), ("Bottleneck5_1", 10, 12), ("Final", 8, 12)]
+
+
+@pytest.mark.parametrize("name,h,w", _layer_cases())
+def test_single_layer_bit_exact(enet_c3k19, name, h, w):
+    net, P = enet_c3k19
+    layer = getattr(net, name)
+    kind = type(layer).__name__
+    cin = {"Initial": 3, "Final": 16}.get(name)
+    if cin is None:
+        cin = layer.proj_kernel.shape[2]
+    rng = np.random.default_rng(16)
+    x = rng.normal(size=(2, h, w, cin)).astype(np.float32)
+    dil = layer.dilation_rate[0] if kind == "Bottleneck" else 1
+    if kind == "Initial":
+        report_diff(name, layer(dev(x), training=False).cpu().numpy(), orc.initial(P, name, x))
+    elif kind == "Bottleneck":
+        want = orc.bottleneck(P, name, x, dil=dil, asym=layer.asymmetric)
+        report_diff(name, layer(dev(x), training=False).cpu().numpy(), want)
+    elif kind == "BottleneckDownsample":
+        want, want_arg = orc.bottleneck_down(P, name, x)
+        y, arg = layer(dev(x), training=False)
+        report_diff(name, y.cpu().numpy(), want)
+        report_diff(name + " argmax (bit-exact)", arg.cpu().numpy(), want_arg)
+    elif kind == "BottleneckUpsample":
+        cout = layer.output_channels
+        pre = rng.normal(size=(2, 2 * h, 2 * w, cout)).astype(np.float32)
+        _, arg = orc.maxpool2x2_argmax(pre)
+        want = orc.bottleneck_up(P, name, x, arg)
+        report_diff(name, layer(dev(x), dev(arg), training=False).cpu().numpy(), want)
+    else:
+        report_diff(name, layer(dev(x)).cpu().numpy(), orc.final(P, name, x))
+
+
+# ---- whole network -------------------------------------------------------------------------------
+def _check_forward(net, P, x, tag):
+    ep = {}
+    want = orc.enet_forward(P, x, ep)
+    got = net(dev(x), training=False).cpu().numpy()
+    final, b5_1, b4_2, b3_8 = net.endpoint_outputs[-1]
+    report_diff(tag + " bottleneck3_8", b3_8.cpu().numpy(), ep["Bottleneck3_8"])
+    report_diff(tag + " bottleneck4_2", b4_2.cpu().numpy(), ep["Bottleneck4_2"])
+    report_diff(tag + " bottleneck5_1", b5_1.cpu().numpy(), ep["Bottleneck5_1"])
+    report_diff(tag + " logits vs C oracle (bit-exact)", got, want)
+    wb = tr.enet_forward(P, x)
+    report_diff(tag + " logits vs torch restatement", got, wb, exact=False, atol=TOL)
+    return got, want
+
+
+def test_forward_c1_256x512(enet_c3k19):
+    """BASELINE config C1: 4 synthetic 256x512x3 frames, K=19: forward + entropy + top-1"""
+    net, P = enet_c3k19
+    x = frames([0, 1, 2, 3], 256, 512, 3)
+    got, want = _check_forward(net, P, x, "C1")
+    want_mean, want_conf, want_label = orc.score_logits(want, "entropy")
+    scores, extra = net.score(dev(x), "entropy", return_label=True, return_confidence=True)
+    report_diff("C1 pseudo_label (bit-exact argmax)", extra["label"].cpu().numpy(), want_label)
+    report_diff("C1 confidence", extra["confidence"].cpu().numpy(), want_conf, exact=False, atol=TOL)
+    report_diff("C1 mean confidence", scores.cpu().numpy(), want_mean, exact=False, atol=1e-6)
+    low, _ = al.finish_ranking(np.arange(4), scores.cpu().numpy(), 4, np.arange(4), 1)
+    want_low, _ = orc.rank_lowest(want_mean, np.arange(4), 1)
+    assert low.tolist() == want_low.tolist()
+
+
+def test_forward_matches_golden_fixture(enet_c3k19):
+    net, P = enet_c3k19
+    g = np.load(os.path.join(GOLDEN, "enet_c3k19_64x128.npz"))
+    x = frames(list(g["frame_ids"]), 64, 128, 3)
+    got = net(dev(x), training=False).cpu().numpy()
+    report_diff("logits vs golden", got, g["logits"])
+    for m in ("entropy", "margin", "confidence"):
+        scores, extra = net.score(dev(x), m, return_label=True, return_confidence=True)
+        report_diff(m + " label vs golden", extra["label"].cpu().numpy(), g["label"])
+        report_diff(m + " conf vs golden", extra["confidence"].cpu().numpy()[0], g["conf_" + m], exact=False, atol=TOL)
+        report_diff(m + " mean vs golden", scores.cpu().numpy(), g["mean_" + m], exact=False, atol=1e-6)
+
+
+def test_forward_c5_rgb_nir_6_classes(enet_c4k6):
+    """BASELINE config C5 shape family: 4-channel input (RGB+NIR), 6 classes"""
+    net, P = enet_c4k6
+    g = np.load(os.path.join(GOLDEN, "enet_c4k6_64x64.npz"))
+    x = frames(list(g["frame_ids"]), 64, 64, 4)
+    got, _ = _check_forward(net, P, x, "C5")
+    report_diff("C5 logits vs golden", got, g["logits"])
+    scores = net.score(dev(x), "entropy")
+    report_diff("C5 mean", scores.cpu().numpy(), g["mean_entropy"], exact=False, atol=1e-6)
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 8, 8), (3, 24, 40), (1, 136, 72), (5, 16, 8)])
+def test_forward_ragged_shapes(enet_c3k19, n, h, w):
+    net, P = enet_c3k19
+    x = frames(range(20, 20 + n), h, w, 3)
+    _check_forward(net, P, x, "%dx%dx%d" % (n, h, w))
+
+
+def test_fused_score_equals_unfused_path(enet_c3k19):
+    """the fused Final+score kernel and (logits -> stand-alone score kernel) agree"""
+    net, _ = enet_c3k19
+    x = dev(frames([7, 8], 64, 128, 3))
+    logits = net(x, training=False)
+    for m in ("entropy", "margin", "confidence"):
+        a, ea = net.score(x, m, threshold=0.3, return_label=True, return_mask=True, return_confidence=True)
+        b, eb = al.score_logits(logits, m, threshold=0.3, return_label=True, return_mask=True, return_confidence=True)
+        assert torch.equal(ea["label"], eb["label"]) and torch.equal(ea["mask"], eb["mask"])
+        assert torch.equal(ea["confidence"], eb["confidence"])
+        assert float((a - b).abs().max()) < 1e-12
+
+
+def test_score_is_bitwise_reproducible(enet_c3k19):
+    net, _ = enet_c3k19
+    x = dev(frames([3, 4, 5], 64, 128, 3))
+    a = net.score(x, "entropy").clone()
+    b = net.score(x, "entropy").clone()
+    assert torch.equal(a, b)
+    # batch-size independence: images are independent at inference
+    c = torch.cat([net.score(x[i:i + 1], "entropy") for i in range(3)])
+    assert torch.equal(a, c)
+
+
+def test_weight_update_is_picked_up(enet_c3k19):
+    net, P = enet_c3k19
+    x = frames([1], 32, 32, 3)
+    before = net(dev(x), training=False).cpu().numpy()
+    old = net.Final.kernel.numpy().copy()
+    net.Final.kernel.assign(old * np.float32(0.5))  # active_learning.py:461-462 re-initialises Final.kernel
+    try:
+        P2 = dict(P)
+        P2["Final.kernel"] = net.Final.kernel.numpy()
+        after = net(dev(x), training=False).cpu().numpy()
+        report_diff("after assign", after, orc.enet_forward(P2, x))
+        assert not np.array_equal(before, after)
+    finally:
+        net.Final.kernel.assign(old)
+
+
+def test_input_errors(enet_c3k19):
+    net, _ = enet_c3k19
+    with pytest.raises(ValueError, match="divisible by 8"):
+        net(torch.zeros((1, 20, 16, 3), device="cuda"), training=False)
+    with pytest.raises(ValueError):
+        net(torch.zeros((1, 16, 16, 4), device="cuda"), training=False)
+    with pytest.raises(NotImplementedError):
+        net(torch.zeros((1, 16, 16, 3), device="cuda"), training=True)
+    with pytest.raises(NotImplementedError):
+        net.score(torch.zeros((1, 16, 16, 3), device="cuda"), measure="bald")
+
+
+def test_rank_confidence_topk_ids_match_oracle(enet_c3k19):
+    """rank_confidence (active_learning.py:682-715): identical top-k example ids as the oracle"""
+    net, P = enet_c3k19
+    num, bs, k = 13, 4, 3
+    order = np.random.default_rng(17).permutation(num)  # the reference feeds a shuffled order
+    unlabelled = np.array([0, 1, 2, 4, 5, 7, 8, 9, 11, 12])
+
+    def batches():
+        for i in range(0, num, bs):  # last batch is partial (input.py:193-194, no drop_remainder)
+            ids = order[i:i + bs]
+            yield frames(ids, 64, 64, 3), ids
+
+    low, uc = al.rank_confidence(net, batches(), num, unlabelled, k, measure="entropy")
+    want_scores = np.concatenate([orc.score_images(P, frames([i], 64, 64, 3))[0] for i in range(num)])
+    want_low, want_uc = orc.rank_lowest(want_scores, unlabelled, k)
+    gap = np.sort(want_uc)[k] - np.sort(want_uc)[k - 1]
+    assert gap > 1e-4, "fixture must have a decision margin at the k-th boundary (gap=%g)" % gap
+    assert set(low.tolist()) == set(want_low.tolist())
+    assert uc.dtype == np.float32
+    report_diff("unlabelled_confidence", uc, want_uc, exact=False, atol=1e-6)
+
+
+def test_full_resolution_image_bit_exact(enet_c3k19):
+    """BASELINE C2 shape: one 1024x2048x3 frame, checked against the C oracle (~20 s of CPU)"""
+    net, P = enet_c3k19
+    x = frames([100], 1024, 2048, 3)
+    ep = {}
+    want = orc.enet_forward(P, x, ep)
+    xd = dev(x)
+    scores, extra = net.score(xd, "entropy", return_label=True)
+    got = net(xd, training=False).cpu().numpy()
+    report_diff("1024x2048 logits (bit-exact)", got, want)
+    want_mean, _, want_label = orc.score_logits(want, "entropy")
+    report_diff("1024x2048 label", extra["label"].cpu().numpy(), want_label)
+    report_diff("1024x2048 mean", scores.cpu().numpy(), want_mean, exact=False, atol=1e-6)

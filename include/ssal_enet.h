@@ -135,6 +135,14 @@ int ssal_resize_bilinear(const float *x_dev, int n, int h, int w, int c, int oh,
 int ssal_synth_frames_nhwc(uint64_t seed, int64_t first_frame, int count, int h, int w, int c,
                            float *out_dev, void *stream);
 
+/* Kernel-family switch for A/B measurements and cross-checks (no reference counterpart):
+ * 1 = MFMA-fused bottleneck kernels on the shapes they support (default), 0 = generic kernels
+ * everywhere.  Both families produce bit-identical results. */
+int ssal_set_kernel_family(int use_mfma);
+/* hardware-assumption probe used by the tests (v_permlane32_swap / v_permlane16_swap lane
+ * semantics): writes 256 floats */
+int ssal_debug_probe(float *out_dev_256, void *stream);
+
 /* Measurement aid (no reference counterpart): when enabled, every kernel launch is bracketed by
  * HIP events on its own stream; ssal_profile_collect() returns per-kernel launch counts, total
  * milliseconds and ALGORITHMIC flops / bytes as a JSON object.  Single host thread only. */

@@ -44,6 +44,8 @@ PROTOTYPES = {
     "ssal_conv2d_transpose_3x3_s2": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "ssal_resize_bilinear": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ssal_synth_frames_nhwc": (_i, [_c.c_uint64, _i64, _i, _i, _i, _i, _vp, _vp]),
+    "ssal_set_kernel_family": (_i, [_i]),
+    "ssal_debug_probe": (_i, [_vp, _vp]),
     "ssal_profile_enable": (_i, [_i]),
     "ssal_profile_collect": (_i, [_c.c_char_p, _i64]),
 }
@@ -172,3 +174,8 @@ def profile_collect():
     buf = ctypes.create_string_buffer(1 << 16)
     check(lib().ssal_profile_collect(buf, len(buf)))
     return json.loads(buf.value.decode())
+
+
+def set_kernel_family(use_mfma=True):
+    """A/B switch: MFMA-fused bottleneck kernels (default) vs the generic kernels; bit-identical."""
+    check(lib().ssal_set_kernel_family(1 if use_mfma else 0))

@@ -494,11 +494,19 @@ ConvArgs conv_args(const float *x, int N, int H, int W, int Cin, const float *w,
         if (e_ != hipSuccess) return e_;       \
     } while (0)
 
+// kernel-family switch (A/B measurements and cross-checks): 1 = MFMA-fused bottlenecks where the
+// shape is supported (default), 0 = generic kernels everywhere.  Both are bit-identical.
+bool g_use_mfma = true;
+
 // Bottleneck.call (enet_modules.py:526-599)
 hipError_t run_regular(const DevLayer &L, const float *x, int n, int h, int w, float *y,
                        const LayerTemps &T, hipStream_t s)
 {
     const int C = L.cin, f = L.f;
+    if (g_use_mfma && (long)h * w * C < (1L << 31) && bottleneck_mfma_supported(C, f, L.asym))
+        return launch_bottleneck_mfma(x, y, n, h, w, C, L.dil, L.proj_w, L.proj_scale, L.proj_shift,
+                                      L.proj_alpha, L.conv_w, L.conv_scale, L.conv_shift, L.conv_alpha,
+                                      L.exp_w, L.exp_scale, L.exp_shift, L.res_alpha, s);
     ConvArgs p = conv_args(x, n, h, w, C, L.proj_w, 1, 1, f, 1, 1, T.t0);
     p.scale = L.proj_scale; p.shift = L.proj_shift; p.alpha = L.proj_alpha;
     HIP_RET(launch_conv(p, s));
@@ -978,6 +986,19 @@ void prof_end(hipStream_t s)
     if (!g_recs.empty()) (void)hipEventRecord(g_recs.back().b, s);
 }
 }  // namespace ssal
+
+SSAL_API int ssal_set_kernel_family(int use_mfma)
+{
+    g_use_mfma = use_mfma != 0;
+    return SSAL_OK;
+}
+
+SSAL_API int ssal_debug_probe(float *out_dev_256, void *stream)
+{
+    if (!out_dev_256) return fail(SSAL_EINVAL, "NULL device pointer");
+    HIP_TRY(launch_probe_swap(out_dev_256, (hipStream_t)stream));
+    return SSAL_OK;
+}
 
 SSAL_API int ssal_profile_enable(int on)
 {

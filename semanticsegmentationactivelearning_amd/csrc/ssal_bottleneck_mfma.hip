@@ -1,0 +1,448 @@
+// ssal_bottleneck_mfma.hip -- ENet regular / dilated bottleneck (enet_modules.py:526-599) as ONE
+// kernel on the gfx950 matrix cores:  1x1 proj + BN + PReLU -> 3x3 (dilated) conv + BN + PReLU ->
+// 1x1 exp + BN -> + identity residual -> PReLU.  The block input is read once (plus halo) and the
+// block output written once; the C/4-wide intermediates never leave the CU.
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate) is bit-for-bit a k-ordered fmaf
+// chain, and every GEMM below feeds its k-pairs in ascending (kh, kw, ci) order, so the result is
+// bit-identical to the generic kernels and to the parity oracle.
+//
+// Tiling: a dilated 3x3 conv decomposes into dil x dil independent phase sub-images
+// (y = py + dil*r, x = px + dil*c); a workgroup owns a TH x TW tile of ONE phase sub-image, so the
+// halo is always one pixel (in phase space) whatever the dilation.
+//   phase A  proj:  D[pixel][co]  = X[pixel][ci]   * Wp[ci][co]    (halo'd tile, 32-pixel M-tiles)
+//            -> BN + PReLU, zero outside the image, -> LDS  P[(TH+2)*(TW+2)][32 (+2 pad)]
+//   phase B  conv:  D[co][pixel]  = Wc^T[co][tap,ci] * P[tap,ci][pixel]   (9 taps x 32 ci)
+//            -> BN + PReLU in registers; the accumulator tile IS the next A operand (lane = pixel)
+//            exp:   D[pixel][co]  = Q[pixel][ci] * We[ci][co]      (4 N-tiles of 32)
+//            -> BN, + x, PReLU, coalesced 128-B row stores.
+// MFMA 32x32x2 lane maps (l = lane, r = l & 31, h = l >> 5):
+//   A: lane holds A[row r][k = h]    B: lane holds B[k = h][col r]
+//   D: reg i of lane holds D[row (i&3) + 8*(i>>2) + 4*h][col r]
+// An instruction consumes k0 (lanes 0-31) then k1 (lanes 32-63); v_permlane32_swap pairs registers
+// so that consecutive channels sit in the two lane halves (ascending-k accumulation).
+#include "ssal_internal.h"
+#include "ssal_prof.h"
+
+namespace ssal {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// after the call: a = [a.lo | b.lo], b = [a.hi | b.hi]   (lo = lanes 0-31, hi = lanes 32-63)
+__device__ __forceinline__ void swap32(float &a, float &b)
+{
+    u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float prelu1(float v, float a) { return v >= 0.0f ? v : a * v; }
+
+constexpr int F = 32;         // bottleneck width
+constexpr int C = 128;        // block channels
+constexpr int PSTR = F + 2;   // LDS pixel stride in dwords: conflict-free ds_read_b64 / ds_write_b32
+constexpr int PMAX = 352;     // >= (TH+2)*(TW+2) rounded up to a multiple of 32
+
+struct BnkArgs {
+    const float *x;
+    float *y;
+    const float *wp, *ps, *pt, *pa;  // proj kernel [128][32], folded BN, alpha
+    const float *wc, *cs, *ct, *ca;  // conv kernel [3][3][32][32] (HWIO), folded BN, alpha
+    const float *we, *es, *et, *ra;  // exp kernel [32][128], folded BN, residual alpha
+    int N, H, W, dil;
+    int TH;                // tile rows (phase space)
+    int tiles_y, tiles_x;  // tiles per phase sub-image (sized for the largest phase)
+};
+
+// register order in which the swapped conv accumulators deliver ascending channel pairs:
+// 0,2,1,3, 4,6,5,7, ...  (swap bits 0 and 1 of the step index)
+__device__ __host__ constexpr int ord(int s) { return (s & ~3) | ((s & 1) << 1) | ((s >> 1) & 1); }
+
+template <int TW>
+__global__ __launch_bounds__(256, 3) void k_bottleneck_mfma(BnkArgs a)
+{
+    __shared__ float P[PMAX * PSTR];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int d = a.dil;
+    constexpr int HW2 = TW + 2;  // halo'd tile width
+
+    // ---- which (image, phase, tile) is this workgroup? -----------------------------------------
+    int b = blockIdx.x;
+    const int tx = b % a.tiles_x; b /= a.tiles_x;
+    const int ty = b % a.tiles_y; b /= a.tiles_y;
+    const int px = b % d; b /= d;
+    const int py = b % d; b /= d;
+    const int n = b;
+    const int Hp = (a.H - py + d - 1) / d;  // rows / cols of this phase sub-image
+    const int Wp = (a.W - px + d - 1) / d;
+    const int ty0 = ty * a.TH, tx0 = tx * TW;
+    if (ty0 >= Hp || tx0 >= Wp) return;  // whole workgroup: no barrier has been reached yet
+    const int TH = a.TH;
+    const int npix_halo = (TH + 2) * HW2;
+    const float *ximg = a.x + (long)n * a.H * a.W * C;
+
+    // ================= phase A: projection on the halo'd tile -> LDS =============================
+    {
+        // B operand (Wp[ci][co]) for all 64 k-pair steps stays in registers for this wave's M-tiles
+        float wpr[64];
+#pragma unroll
+        for (int s = 0; s < 64; ++s) wpr[s] = a.wp[(2 * s + h) * F + j];
+        const float bs = a.ps[j], bt = a.pt[j], ba = a.pa[j];
+
+        const int nmt = (npix_halo + 31) / 32;
+        for (int mt = wave; mt < nmt; mt += 4) {
+            const int q = mt * 32 + j;
+            const int hr = q / HW2, hc = q - hr * HW2;
+            const int pr = ty0 - 1 + hr, pc = tx0 - 1 + hc;
+            const bool valid = (q < npix_halo) && (pr >= 0) && (pr < Hp) && (pc >= 0) && (pc < Wp);
+            const unsigned long long vmask = __ballot(valid);
+            if (vmask == 0ull) {  // wave-uniform: M-tile entirely outside the image -> zeros
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int qi = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    P[qi * PSTR + j] = 0.0f;
+                }
+                continue;
+            }
+            const float *xp = valid ? ximg + ((long)(py + pr * d) * a.W + (px + pc * d)) * C : ximg;
+            f32x16 acc = {0};
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {  // 32 input channels per chunk
+                float4 v[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m)  // lane half h takes the h-th float4 of every 8 channels
+                    v[m] = *reinterpret_cast<const float4 *>(xp + kc * 32 + (2 * m + h) * 4);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    float a0 = v[m].x, a1 = v[m].y, a2 = v[m].z, a3 = v[m].w;
+                    swap32(a0, a1);  // a0 = ch(8m+0 | 8m+1), a1 = ch(8m+4 | 8m+5)
+                    swap32(a2, a3);  // a2 = ch(8m+2 | 8m+3), a3 = ch(8m+6 | 8m+7)
+                    const int s0 = kc * 16 + m * 4;
+                    acc = mfma32(a0, wpr[s0 + 0], acc);
+                    acc = mfma32(a2, wpr[s0 + 1], acc);
+                    acc = mfma32(a1, wpr[s0 + 2], acc);
+                    acc = mfma32(a3, wpr[s0 + 3], acc);
+                }
+            }
+            // epilogue: rows = pixels (registers), cols = co (lanes): BN + PReLU, zero padding
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ri = (i & 3) + 8 * (i >> 2) + 4 * h;
+                const bool ok = (vmask >> ri) & 1ull;
+                const float v = ok ? prelu1(fmaf(acc[i], bs, bt), ba) : 0.0f;
+                P[(mt * 32 + ri) * PSTR + j] = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ================= phase B: 3x3 conv on P, then expansion + residual ==========================
+    const int nmt_out = (TH * TW) / 32;
+    for (int mt = wave; mt < nmt_out; mt += 4) {
+        const int t = mt * 32 + j;          // this lane's output pixel inside the tile (B operand)
+        const int r = t / TW, c = t - r * TW;
+        f32x16 acc = {0};
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {  // one tap's 16 weight fragments live at a time
+            {
+                const int kh = tap / 3, kw = tap - 3 * kh;
+                const float *pq = P + ((r + kh) * HW2 + (c + kw)) * PSTR + 2 * h;
+                const float *wt = a.wc + (long)(tap * F + h) * F + j;
+#pragma unroll
+                for (int sq = 0; sq < 8; ++sq) {
+                    float2 pv = *reinterpret_cast<const float2 *>(pq + 4 * sq);
+                    float b0 = pv.x, b1 = pv.y;
+                    swap32(b0, b1);  // b0 = ci(4sq | 4sq+1), b1 = ci(4sq+2 | 4sq+3)
+                    const float w0 = wt[(4 * sq) * F];      // Wc[tap][ci = 4sq + h][co = j]
+                    const float w1 = wt[(4 * sq + 2) * F];  // Wc[tap][ci = 4sq + 2 + h][co = j]
+                    acc = mfma32(w0, b0, acc);
+                    acc = mfma32(w1, b1, acc);
+                }
+            }
+        }
+        // conv epilogue: rows = co (registers), cols = pixel (lanes)
+        float qv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int co = (i & 3) + 8 * (i >> 2) + 4 * h;
+            qv[i] = prelu1(fmaf(acc[i], a.cs[co], a.ct[co]), a.ca[co]);
+        }
+        // the accumulator tile becomes the A operand of the expansion GEMM (lane = pixel)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) swap32(qv[2 * u], qv[2 * u + 1]);
+
+        // element offsets (inside image n) of the 16 output rows this lane-half stores
+        int off[16];
+        unsigned okmask = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ti = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const int rr = ti / TW, cc = ti - rr * TW;
+            const int pr = ty0 + rr, pc = tx0 + cc;
+            const bool ok = (pr < Hp) && (pc < Wp);
+            okmask |= ok ? (1u << i) : 0u;
+            off[i] = ok ? ((py + pr * d) * a.W + (px + pc * d)) * C : 0;  // 0 = a safe address
+        }
+        float *yimg = a.y + (long)n * a.H * a.W * C;
+#pragma unroll 1
+        for (int nt = 0; nt < 4; ++nt) {
+            const int co = nt * 32 + j;
+            float rx[16];  // residual rows: issue all loads before the MFMA chain needs them
+#pragma unroll
+            for (int i = 0; i < 16; ++i) rx[i] = ximg[off[i] + co];
+            f32x16 e = {0};
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                e = mfma32(qv[ord(s)], a.we[(2 * s + h) * C + co], e);
+            const float s1 = a.es[co], t1 = a.et[co], al = a.ra[co];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float v = prelu1(fmaf(e[i], s1, t1) + rx[i], al);
+                if ((okmask >> i) & 1u) yimg[off[i] + co] = v;
+            }
+        }
+    }
+}
+
+// =================================================================================================
+// C = 64 / F = 16 variant (stage 1 and stage 4 bottlenecks) on v_mfma_f32_16x16x4_f32.
+// lane maps (l = lane, i = l & 15, g = l >> 4):  A: A[row i][k = g]   B: B[k = g][col i]
+//   D: reg r holds D[row 4*g + r][col i].  One instruction consumes k = 0,1,2,3 (lane quarters) in
+// order, so quarter g must hold channel 4*s + g at step s: registers that hold 4 consecutive
+// channels per lane are transposed across the four quarters with two permlane swaps per pair.
+// =================================================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// after the call (q0..q3 = the four 16-lane quarters):
+//   a = [a.q0 b.q0 a.q2 b.q2], b = [a.q1 b.q1 a.q3 b.q3]
+__device__ __forceinline__ void swap16(float &a, float &b)
+{
+    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+
+// in: reg r of quarter g holds element 4*g + r;  out: reg r of quarter g holds element 4*r + g
+__device__ __forceinline__ void transpose4(float &r0, float &r1, float &r2, float &r3)
+{
+    swap32(r0, r2);  // r0 = [0 4 2 6], r2 = [8 12 10 14]
+    swap32(r1, r3);  // r1 = [1 5 3 7], r3 = [9 13 11 15]
+    swap16(r0, r1);  // r0 = [0 1 2 3], r1 = [4 5 6 7]
+    swap16(r2, r3);  // r2 = [8 9 10 11], r3 = [12 13 14 15]
+}
+
+constexpr int F16 = 16;
+constexpr int C64 = 64;
+constexpr int PSTR16 = F16 + 2;  // conflict-free ds_read_b32 for 16 consecutive pixels x 2 quarters
+
+template <int TW>
+__global__ __launch_bounds__(256, 4) void k_bottleneck_mfma_f16(BnkArgs a)
+{
+    __shared__ float P[PMAX * PSTR16];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int d = a.dil;
+    constexpr int HW2 = TW + 2;
+
+    int b = blockIdx.x;
+    const int tx = b % a.tiles_x; b /= a.tiles_x;
+    const int ty = b % a.tiles_y; b /= a.tiles_y;
+    const int px = b % d; b /= d;
+    const int py = b % d; b /= d;
+    const int n = b;
+    const int Hp = (a.H - py + d - 1) / d;
+    const int Wp = (a.W - px + d - 1) / d;
+    const int ty0 = ty * a.TH, tx0 = tx * TW;
+    if (ty0 >= Hp || tx0 >= Wp) return;
+    const int TH = a.TH;
+    const int npix_halo = (TH + 2) * HW2;
+    const float *ximg = a.x + (long)n * a.H * a.W * C64;
+
+    // ---- phase A: projection (64 -> 16) on the halo'd tile ---------------------------------------
+    {
+        float wpr[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) wpr[s] = a.wp[(4 * s + g) * F16 + i16];
+        const float bs = a.ps[i16], bt = a.pt[i16], ba = a.pa[i16];
+        const int nmt = (npix_halo + 15) / 16;
+        for (int mt = wave; mt < nmt; mt += 4) {
+            const int q = mt * 16 + i16;
+            const int hr = q / HW2, hc = q - hr * HW2;
+            const int pr = ty0 - 1 + hr, pc = tx0 - 1 + hc;
+            const bool valid = (q < npix_halo) && (pr >= 0) && (pr < Hp) && (pc >= 0) && (pc < Wp);
+            const unsigned vmask = (unsigned)(__ballot(valid) & 0xFFFFull);
+            if (vmask == 0u) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) P[(mt * 16 + 4 * g + r) * PSTR16 + i16] = 0.0f;
+                continue;
+            }
+            const float *xp = valid ? ximg + ((long)(py + pr * d) * a.W + (px + pc * d)) * C64 : ximg;
+            float4 v[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)  // quarter g takes the g-th float4 of every 16 channels
+                v[m] = *reinterpret_cast<const float4 *>(xp + 16 * m + 4 * g);
+            f32x4 acc = {0};
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                float r0 = v[m].x, r1 = v[m].y, r2 = v[m].z, r3 = v[m].w;
+                transpose4(r0, r1, r2, r3);  // reg r of quarter g: channel 16m + 4r + g
+                acc = mfma16(r0, wpr[4 * m + 0], acc);
+                acc = mfma16(r1, wpr[4 * m + 1], acc);
+                acc = mfma16(r2, wpr[4 * m + 2], acc);
+                acc = mfma16(r3, wpr[4 * m + 3], acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pix = 4 * g + r;
+                const bool ok = (vmask >> pix) & 1u;
+                P[(mt * 16 + pix) * PSTR16 + i16] = ok ? prelu1(fmaf(acc[r], bs, bt), ba) : 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: 3x3 conv (16 -> 16) on P, expansion (16 -> 64) + residual ----------------------
+    float cs[4], ct[4], ca[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        cs[r] = a.cs[4 * g + r];
+        ct[r] = a.ct[4 * g + r];
+        ca[r] = a.ca[4 * g + r];
+    }
+    float *yimg = a.y + (long)n * a.H * a.W * C64;
+    const int nmt_out = (TH * TW) / 16;
+    for (int mt = wave; mt < nmt_out; mt += 4) {
+        const int t = mt * 16 + i16;
+        const int r_ = t / TW, c_ = t - r_ * TW;
+        f32x4 acc = {0};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            const float *pq = P + ((r_ + kh) * HW2 + (c_ + kw)) * PSTR16 + g;
+            const float *wt = a.wc + (tap * F16 + g) * F16 + i16;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)  // ci = 4s + g: ascending across the lane quarters
+                acc = mfma16(wt[(4 * s) * F16], pq[4 * s], acc);
+        }
+        float q0 = prelu1(fmaf(acc[0], cs[0], ct[0]), ca[0]);
+        float q1 = prelu1(fmaf(acc[1], cs[1], ct[1]), ca[1]);
+        float q2 = prelu1(fmaf(acc[2], cs[2], ct[2]), ca[2]);
+        float q3 = prelu1(fmaf(acc[3], cs[3], ct[3]), ca[3]);
+        transpose4(q0, q1, q2, q3);  // reg s of quarter g: Q[pixel i16][ci = 4s + g]
+
+        int off[4];
+        unsigned okmask = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ti = mt * 16 + 4 * g + r;
+            const int rr = ti / TW, cc = ti - rr * TW;
+            const int pr = ty0 + rr, pc = tx0 + cc;
+            const bool ok = (pr < Hp) && (pc < Wp);
+            okmask |= ok ? (1u << r) : 0u;
+            off[r] = ok ? ((py + pr * d) * a.W + (px + pc * d)) * C64 : 0;
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int co = nt * 16 + i16;
+            float rx[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rx[r] = ximg[off[r] + co];
+            f32x4 e = {0};
+            e = mfma16(q0, a.we[(0 + g) * C64 + co], e);
+            e = mfma16(q1, a.we[(4 + g) * C64 + co], e);
+            e = mfma16(q2, a.we[(8 + g) * C64 + co], e);
+            e = mfma16(q3, a.we[(12 + g) * C64 + co], e);
+            const float s1 = a.es[co], t1 = a.et[co], al = a.ra[co];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = prelu1(fmaf(e[r], s1, t1) + rx[r], al);
+                if ((okmask >> r) & 1u) yimg[off[r] + co] = v;
+            }
+        }
+    }
+}
+
+// one probe for the hardware assumptions this file rests on (tests only): out[0..63] / out[64..127]
+// = the two registers after swap32 of (lane, 100 + lane)
+__global__ void k_probe_swap(float *out)
+{
+    float a = (float)threadIdx.x, b = 100.0f + (float)threadIdx.x;
+    swap32(a, b);
+    out[threadIdx.x] = a;
+    out[64 + threadIdx.x] = b;
+    float c = (float)threadIdx.x, e = 100.0f + (float)threadIdx.x;
+    swap16(c, e);
+    out[128 + threadIdx.x] = c;
+    out[192 + threadIdx.x] = e;
+}
+
+hipError_t launch_probe_swap(float *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_probe_swap, dim3(1), dim3(64), 0, s, out);
+    return hipGetLastError();
+}
+
+bool bottleneck_mfma_supported(int Cin, int f, bool asym)
+{
+    return !asym && ((Cin == C && f == F) || (Cin == C64 && f == F16));
+}
+
+hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W, int Cin, int dil,
+                                  const float *wp, const float *ps, const float *pt, const float *pa,
+                                  const float *wc, const float *cs, const float *ct, const float *ca,
+                                  const float *we, const float *es, const float *et, const float *ra,
+                                  hipStream_t s)
+{
+    if (dil < 1 || dil > 64) return hipErrorInvalidValue;
+    BnkArgs a;
+    a.x = x; a.y = y;
+    a.wp = wp; a.ps = ps; a.pt = pt; a.pa = pa;
+    a.wc = wc; a.cs = cs; a.ct = ct; a.ca = ca;
+    a.we = we; a.es = es; a.et = et; a.ra = ra;
+    a.N = N; a.H = H; a.W = W; a.dil = dil;
+    a.TH = 8;
+    const int Hp = (H + dil - 1) / dil, Wp = (W + dil - 1) / dil;  // largest phase sub-image
+    const bool wide = Wp > 16;
+    const int TW = wide ? 32 : 16;
+    a.tiles_y = (Hp + a.TH - 1) / a.TH;
+    a.tiles_x = (Wp + TW - 1) / TW;
+    const long grid = (long)N * dil * dil * a.tiles_y * a.tiles_x;
+    if (grid <= 0 || grid > 0x7fffffffL) return hipErrorInvalidValue;
+    const double pix = (double)N * H * W;
+    const double f = Cin / 4.0;
+    ProfScope prof(Cin == C ? "k_bottleneck_mfma" : "k_bottleneck_mfma_f16",
+                   2.0 * pix * (Cin * f + 9.0 * f * f + f * Cin),
+                   4.0 * (2.0 * pix * Cin + Cin * f * 2.0 + 9.0 * f * f), s);
+    if (Cin == C) {
+        if (wide)
+            hipLaunchKernelGGL(k_bottleneck_mfma<32>, dim3((unsigned)grid), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL(k_bottleneck_mfma<16>, dim3((unsigned)grid), dim3(256), 0, s, a);
+    } else if (Cin == C64) {
+        if (wide)
+            hipLaunchKernelGGL(k_bottleneck_mfma_f16<32>, dim3((unsigned)grid), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL(k_bottleneck_mfma_f16<16>, dim3((unsigned)grid), dim3(256), 0, s, a);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace ssal

@@ -68,6 +68,15 @@ hipError_t launch_unpool_scatter(const float *x, const int64_t *idx, int N, int 
 hipError_t launch_codes_to_argmax(const uint8_t *code, int N, int Ho, int Wo, int C,
                                   int64_t *argmax, hipStream_t s);
 
+// MFMA-fused regular / dilated bottleneck (ssal_bottleneck_mfma.hip)
+bool bottleneck_mfma_supported(int Cin, int f, bool asym);
+hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W, int Cin, int dil,
+                                  const float *wp, const float *ps, const float *pt, const float *pa,
+                                  const float *wc, const float *cs, const float *ct, const float *ca,
+                                  const float *we, const float *es, const float *et, const float *ra,
+                                  hipStream_t s);
+hipError_t launch_probe_swap(float *out, hipStream_t s);
+
 hipError_t launch_prelu(const float *x, int64_t pixels, int C, const float *alpha, float *y,
                         hipStream_t s);
 hipError_t launch_affine(const float *x, int64_t pixels, int C, const float *scale,

@@ -210,6 +210,47 @@ def test_single_layer_bit_exact(enet_c3k19, name, h, w):
         report_diff(name, layer(dev(x)).cpu().numpy(), orc.final(P, name, x))
 
 
+# ---- MFMA-fused bottleneck kernels: hardware assumptions + equality with the generic family --------
+def test_permlane32_swap_lane_semantics():
+    """swap32(a, b) must give a = [a.lo | b.lo], b = [a.hi | b.hi] (ssal_bottleneck_mfma.hip relies on it)"""
+    out = torch.zeros(256, dtype=torch.float32, device="cuda")
+    _lib.check(_lib.lib().ssal_debug_probe(_lib.dev_ptr(out), _lib.stream_ptr()))
+    got = out.cpu().numpy()
+    lane = np.arange(64, dtype=np.float32)
+    a, b = lane, 100 + lane
+    assert (got[:64] == np.concatenate([a[:32], b[:32]])).all(), got[:64]
+    assert (got[64:128] == np.concatenate([a[32:], b[32:]])).all(), got[64:128]
+    # swap16(a, b): a = [a.q0 b.q0 a.q2 b.q2], b = [a.q1 b.q1 a.q3 b.q3]  (q = 16-lane quarters)
+    qa, qb = a.reshape(4, 16), b.reshape(4, 16)
+    assert (got[128:192] == np.concatenate([qa[0], qb[0], qa[2], qb[2]])).all(), got[128:192]
+    assert (got[192:256] == np.concatenate([qa[1], qb[1], qa[3], qb[3]])).all(), got[192:256]
+
+
+@pytest.mark.parametrize("name,n,h,w", [
+    ("Bottleneck2_1", 2, 16, 32), ("Bottleneck2_1", 1, 9, 11), ("Bottleneck2_1", 1, 8, 40), ("Bottleneck2_2", 2, 16, 32),
+    ("Bottleneck2_2", 1, 17, 35), ("Bottleneck2_4", 1, 32, 64), ("Bottleneck2_4", 2, 12, 9), ("Bottleneck2_6", 1, 18, 20),
+    ("Bottleneck2_6", 1, 32, 64), ("Bottleneck2_8", 1, 34, 36), ("Bottleneck3_8", 2, 32, 64), ("Bottleneck3_5", 3, 24, 72),
+    ("Bottleneck3_8", 1, 16, 16), ("Bottleneck2_1", 1, 1, 1),
+    ("Bottleneck1_1", 2, 16, 32), ("Bottleneck1_3", 1, 9, 11), ("Bottleneck1_4", 1, 24, 72), ("Bottleneck4_1", 2, 32, 64),
+    ("Bottleneck4_2", 1, 1, 1), ("Bottleneck1_2", 1, 8, 40),
+])
+def test_mfma_bottleneck_equals_generic_and_oracle(enet_c3k19, name, n, h, w):
+    net, P = enet_c3k19
+    layer = getattr(net, name)
+    x = np.random.default_rng(18).normal(size=(n, h, w, layer.output_channels)).astype(np.float32)
+    want = orc.bottleneck(P, name, x, dil=layer.dilation_rate[0], asym=False)
+    xd = dev(x)
+    try:
+        _lib.set_kernel_family(True)
+        got_mfma = layer(xd, training=False).cpu().numpy()
+        _lib.set_kernel_family(False)
+        got_gen = layer(xd, training=False).cpu().numpy()
+    finally:
+        _lib.set_kernel_family(True)
+    report_diff(name + " generic vs oracle", got_gen, want)
+    report_diff(name + " MFMA vs oracle (bit-exact)", got_mfma, want)
+
+
 # ---- whole network -------------------------------------------------------------------------------
 def _check_forward(net, P, x, tag):
     ep = {}

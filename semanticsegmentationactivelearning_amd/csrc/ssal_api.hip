@@ -505,8 +505,9 @@ hipError_t run_regular(const DevLayer &L, const float *x, int n, int h, int w, f
     const int C = L.cin, f = L.f;
     if (g_use_mfma && (long)h * w * C < (1L << 31) && bottleneck_mfma_supported(C, f, L.asym))
         return launch_bottleneck_mfma(x, y, n, h, w, C, L.dil, L.proj_w, L.proj_scale, L.proj_shift,
-                                      L.proj_alpha, L.conv_w, L.conv_scale, L.conv_shift, L.conv_alpha,
-                                      L.exp_w, L.exp_scale, L.exp_shift, L.res_alpha, s);
+                                      L.proj_alpha, L.conv_w, L.asym ? L.conv_w1 : nullptr,
+                                      L.conv_scale, L.conv_shift, L.conv_alpha, L.exp_w, L.exp_scale,
+                                      L.exp_shift, L.res_alpha, s);
     ConvArgs p = conv_args(x, n, h, w, C, L.proj_w, 1, 1, f, 1, 1, T.t0);
     p.scale = L.proj_scale; p.shift = L.proj_shift; p.alpha = L.proj_alpha;
     HIP_RET(launch_conv(p, s));

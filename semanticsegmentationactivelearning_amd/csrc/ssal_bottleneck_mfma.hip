@@ -53,7 +53,8 @@ struct BnkArgs {
     const float *x;
     float *y;
     const float *wp, *ps, *pt, *pa;  // proj kernel [128][32], folded BN, alpha
-    const float *wc, *cs, *ct, *ca;  // conv kernel [3][3][32][32] (HWIO), folded BN, alpha
+    const float *wc, *cs, *ct, *ca;  // conv kernel [3][3][32][32] (HWIO; [5][1][32][32] if asym), folded BN, alpha
+    const float *wc2;                // asymmetric only: second kernel [1][5][32][32]
     const float *we, *es, *et, *ra;  // exp kernel [32][128], folded BN, residual alpha
     int N, H, W, dil;
     int TH;                // tile rows (phase space)
@@ -64,110 +65,144 @@ struct BnkArgs {
 // 0,2,1,3, 4,6,5,7, ...  (swap bits 0 and 1 of the step index)
 __device__ __host__ constexpr int ord(int s) { return (s & ~3) | ((s & 1) << 1) | ((s >> 1) & 1); }
 
-template <int TW>
-__global__ __launch_bounds__(256, 3) void k_bottleneck_mfma(BnkArgs a)
+// ---- phase A (shared by the regular and the asymmetric kernel): 1x1 projection + BN + PReLU of the
+// halo'd tile into LDS; pixels outside the image are written as exact zeros (SAME padding of the
+// following conv applies to the PROJECTED tensor).  HALO = 1 (3x3) or 2 (5x1 / 1x5).
+template <int TW, int HALO>
+__device__ __forceinline__ void proj_to_lds(const BnkArgs &a, const float *ximg, float *P, int TH,
+                                            int ty0, int tx0, int py, int px, int Hp, int Wp,
+                                            int wave, int j, int h)
 {
-    __shared__ float P[PMAX * PSTR];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, h = lane >> 5;
+    constexpr int HWP = TW + 2 * HALO;
     const int d = a.dil;
-    constexpr int HW2 = TW + 2;  // halo'd tile width
+    const int npix_halo = (TH + 2 * HALO) * HWP;
+    // B operand (Wp[ci][co]) for all 64 k-pair steps stays in registers for this wave's M-tiles
+    float wpr[64];
+#pragma unroll
+    for (int s = 0; s < 64; ++s) wpr[s] = a.wp[(2 * s + h) * F + j];
+    const float bs = a.ps[j], bt = a.pt[j], ba = a.pa[j];
 
-    // ---- which (image, phase, tile) is this workgroup? -----------------------------------------
-    int b = blockIdx.x;
-    const int tx = b % a.tiles_x; b /= a.tiles_x;
-    const int ty = b % a.tiles_y; b /= a.tiles_y;
-    const int px = b % d; b /= d;
-    const int py = b % d; b /= d;
-    const int n = b;
-    const int Hp = (a.H - py + d - 1) / d;  // rows / cols of this phase sub-image
-    const int Wp = (a.W - px + d - 1) / d;
-    const int ty0 = ty * a.TH, tx0 = tx * TW;
-    if (ty0 >= Hp || tx0 >= Wp) return;  // whole workgroup: no barrier has been reached yet
-    const int TH = a.TH;
-    const int npix_halo = (TH + 2) * HW2;
-    const float *ximg = a.x + (long)n * a.H * a.W * C;
-
-    // ================= phase A: projection on the halo'd tile -> LDS =============================
-    {
-        // B operand (Wp[ci][co]) for all 64 k-pair steps stays in registers for this wave's M-tiles
-        float wpr[64];
-#pragma unroll
-        for (int s = 0; s < 64; ++s) wpr[s] = a.wp[(2 * s + h) * F + j];
-        const float bs = a.ps[j], bt = a.pt[j], ba = a.pa[j];
-
-        const int nmt = (npix_halo + 31) / 32;
-        for (int mt = wave; mt < nmt; mt += 4) {
-            const int q = mt * 32 + j;
-            const int hr = q / HW2, hc = q - hr * HW2;
-            const int pr = ty0 - 1 + hr, pc = tx0 - 1 + hc;
-            const bool valid = (q < npix_halo) && (pr >= 0) && (pr < Hp) && (pc >= 0) && (pc < Wp);
-            const unsigned long long vmask = __ballot(valid);
-            if (vmask == 0ull) {  // wave-uniform: M-tile entirely outside the image -> zeros
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int qi = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    P[qi * PSTR + j] = 0.0f;
-                }
-                continue;
-            }
-            const float *xp = valid ? ximg + ((long)(py + pr * d) * a.W + (px + pc * d)) * C : ximg;
-            f32x16 acc = {0};
-#pragma unroll
-            for (int kc = 0; kc < 4; ++kc) {  // 32 input channels per chunk
-                float4 v[4];
-#pragma unroll
-                for (int m = 0; m < 4; ++m)  // lane half h takes the h-th float4 of every 8 channels
-                    v[m] = *reinterpret_cast<const float4 *>(xp + kc * 32 + (2 * m + h) * 4);
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    float a0 = v[m].x, a1 = v[m].y, a2 = v[m].z, a3 = v[m].w;
-                    swap32(a0, a1);  // a0 = ch(8m+0 | 8m+1), a1 = ch(8m+4 | 8m+5)
-                    swap32(a2, a3);  // a2 = ch(8m+2 | 8m+3), a3 = ch(8m+6 | 8m+7)
-                    const int s0 = kc * 16 + m * 4;
-                    acc = mfma32(a0, wpr[s0 + 0], acc);
-                    acc = mfma32(a2, wpr[s0 + 1], acc);
-                    acc = mfma32(a1, wpr[s0 + 2], acc);
-                    acc = mfma32(a3, wpr[s0 + 3], acc);
-                }
-            }
-            // epilogue: rows = pixels (registers), cols = co (lanes): BN + PReLU, zero padding
+    const int nmt = (npix_halo + 31) / 32;
+    for (int mt = wave; mt < nmt; mt += 4) {
+        const int q = mt * 32 + j;
+        const int hr = q / HWP, hc = q - hr * HWP;
+        const int pr = ty0 - HALO + hr, pc = tx0 - HALO + hc;
+        const bool valid = (q < npix_halo) && (pr >= 0) && (pr < Hp) && (pc >= 0) && (pc < Wp);
+        const unsigned long long vmask = __ballot(valid);
+        if (vmask == 0ull) {  // wave-uniform: M-tile entirely outside the image -> zeros
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int ri = (i & 3) + 8 * (i >> 2) + 4 * h;
-                const bool ok = (vmask >> ri) & 1ull;
-                const float v = ok ? prelu1(fmaf(acc[i], bs, bt), ba) : 0.0f;
-                P[(mt * 32 + ri) * PSTR + j] = v;
+                const int qi = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                P[qi * PSTR + j] = 0.0f;
+            }
+            continue;
+        }
+        const float *xp = valid ? ximg + ((long)(py + pr * d) * a.W + (px + pc * d)) * C : ximg;
+        f32x16 acc = {0};
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {  // 32 input channels per chunk
+            float4 v[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)  // lane half h takes the h-th float4 of every 8 channels
+                v[m] = *reinterpret_cast<const float4 *>(xp + kc * 32 + (2 * m + h) * 4);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                float a0 = v[m].x, a1 = v[m].y, a2 = v[m].z, a3 = v[m].w;
+                swap32(a0, a1);  // a0 = ch(8m+0 | 8m+1), a1 = ch(8m+4 | 8m+5)
+                swap32(a2, a3);  // a2 = ch(8m+2 | 8m+3), a3 = ch(8m+6 | 8m+7)
+                const int s0 = kc * 16 + m * 4;
+                acc = mfma32(a0, wpr[s0 + 0], acc);
+                acc = mfma32(a2, wpr[s0 + 1], acc);
+                acc = mfma32(a1, wpr[s0 + 2], acc);
+                acc = mfma32(a3, wpr[s0 + 3], acc);
             }
         }
+        // epilogue: rows = pixels (registers), cols = co (lanes): BN + PReLU, zero padding
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ri = (i & 3) + 8 * (i >> 2) + 4 * h;
+            const bool ok = (vmask >> ri) & 1ull;
+            const float v = ok ? prelu1(fmaf(acc[i], bs, bt), ba) : 0.0f;
+            P[(mt * 32 + ri) * PSTR + j] = v;
+        }
     }
-    __syncthreads();
+}
 
-    // ================= phase B: 3x3 conv on P, then expansion + residual ==========================
-    const int nmt_out = (TH * TW) / 32;
-    for (int mt = wave; mt < nmt_out; mt += 4) {
-        const int t = mt * 32 + j;          // this lane's output pixel inside the tile (B operand)
-        const int r = t / TW, c = t - r * TW;
+// ---- asymmetric only: R1 = conv (5,1) of P, no BN / activation (enet_modules.py:553-558), for the
+// TH x (TW+4) pixels the (1,5) conv needs; D[pixel][co] = P[pixel + kh][ci] * W0[kh][ci][co] -> LDS.
+template <int TW>
+__device__ __forceinline__ void conv5x1_to_lds(const BnkArgs &a, const float *P, float *R, int TH,
+                                               int wave, int j, int h)
+{
+    constexpr int HWP = TW + 4;
+    const int nmt = (TH * HWP) / 32;  // TH = 8: 9 (TW 32) or 5 (TW 16) whole M-tiles
+    for (int mt = wave; mt < nmt; mt += 4) {
+        const int u = mt * 32 + j;
         f32x16 acc = {0};
 #pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {  // one tap's 16 weight fragments live at a time
-            {
-                const int kh = tap / 3, kw = tap - 3 * kh;
-                const float *pq = P + ((r + kh) * HW2 + (c + kw)) * PSTR + 2 * h;
-                const float *wt = a.wc + (long)(tap * F + h) * F + j;
+        for (int kh = 0; kh < 5; ++kh) {
+            const float *pq = P + (u + kh * HWP) * PSTR + 2 * h;  // pixel (r + kh, c') = u + kh*HWP
+            const float *wt = a.wc + (long)(kh * F + h) * F + j;
 #pragma unroll
-                for (int sq = 0; sq < 8; ++sq) {
-                    float2 pv = *reinterpret_cast<const float2 *>(pq + 4 * sq);
-                    float b0 = pv.x, b1 = pv.y;
-                    swap32(b0, b1);  // b0 = ci(4sq | 4sq+1), b1 = ci(4sq+2 | 4sq+3)
-                    const float w0 = wt[(4 * sq) * F];      // Wc[tap][ci = 4sq + h][co = j]
-                    const float w1 = wt[(4 * sq + 2) * F];  // Wc[tap][ci = 4sq + 2 + h][co = j]
-                    acc = mfma32(w0, b0, acc);
-                    acc = mfma32(w1, b1, acc);
-                }
+            for (int sq = 0; sq < 8; ++sq) {
+                float2 pv = *reinterpret_cast<const float2 *>(pq + 4 * sq);
+                float a0 = pv.x, a1 = pv.y;
+                swap32(a0, a1);  // a0 = ci(4sq | 4sq+1), a1 = ci(4sq+2 | 4sq+3)
+                acc = mfma32(a0, wt[(4 * sq) * F], acc);
+                acc = mfma32(a1, wt[(4 * sq + 2) * F], acc);
             }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ri = (i & 3) + 8 * (i >> 2) + 4 * h;
+            R[(mt * 32 + ri) * PSTR + j] = acc[i];
+        }
+    }
+}
+
+// ---- last phase: KH x KW conv over an LDS tensor S (row stride SW pixels) + BN + PReLU, then the
+// 1x1 expansion + BN + residual + PReLU straight to HBM.
+template <int TW, int KH, int KW, int SW>
+__device__ __forceinline__ void conv_exp_store(const BnkArgs &a, const float *ximg, float *yimg,
+                                               const float *S, const float *wconv, int TH, int ty0,
+                                               int tx0, int py, int px, int Hp, int Wp, int wave,
+                                               int j, int h)
+{
+    const int d = a.dil;
+    const int nmt_out = (TH * TW) / 32;
+    for (int mt = wave; mt < nmt_out; mt += 4) {
+        const int t = mt * 32 + j;  // this lane's output pixel inside the tile (B operand)
+        const int r = t / TW, c = t - r * TW;
+        f32x16 acc = {0};
+        // software pipeline: the 16 weight fragments of tap t+1 are requested before the 16 MFMAs of
+        // tap t are issued, so their L2 latency hides behind ~1000 cycles of matrix work
+        float wcur[16];
+        {
+            const float *wt = wconv + (long)h * F + j;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) wcur[k] = wt[(2 * k) * F];  // W[0][ci = 2k + h][co = j]
+        }
+#pragma unroll 1
+        for (int tap = 0; tap < KH * KW; ++tap) {
+            const int kh = tap / KW, kw = tap - KW * kh;
+            const int tn = tap + 1 < KH * KW ? tap + 1 : tap;
+            float wnxt[16];
+            {
+                const float *wt = wconv + (long)(tn * F + h) * F + j;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) wnxt[k] = wt[(2 * k) * F];
+            }
+            const float *pq = S + ((r + kh) * SW + (c + kw)) * PSTR + 2 * h;
+#pragma unroll
+            for (int sq = 0; sq < 8; ++sq) {
+                float2 pv = *reinterpret_cast<const float2 *>(pq + 4 * sq);
+                float b0 = pv.x, b1 = pv.y;
+                swap32(b0, b1);  // b0 = ci(4sq | 4sq+1), b1 = ci(4sq+2 | 4sq+3)
+                acc = mfma32(wcur[2 * sq], b0, acc);      // W[tap][ci = 4sq + h][co = j]
+                acc = mfma32(wcur[2 * sq + 1], b1, acc);  // W[tap][ci = 4sq + 2 + h][co = j]
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) wcur[k] = wnxt[k];
         }
         // conv epilogue: rows = co (registers), cols = pixel (lanes)
         float qv[16];
@@ -192,25 +227,99 @@ __global__ __launch_bounds__(256, 3) void k_bottleneck_mfma(BnkArgs a)
             okmask |= ok ? (1u << i) : 0u;
             off[i] = ok ? ((py + pr * d) * a.W + (px + pc * d)) * C : 0;  // 0 = a safe address
         }
-        float *yimg = a.y + (long)n * a.H * a.W * C;
+        // expansion: operands of N-tile nt+1 (16 weight fragments, 16 residual rows, 3 constants) are
+        // requested before the MFMA chain of N-tile nt runs
+        float wecur[16], rxcur[16];
+        float s1 = a.es[j], t1 = a.et[j], al = a.ra[j];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) wecur[k] = a.we[(2 * k + h) * C + j];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rxcur[i] = ximg[off[i] + j];
 #pragma unroll 1
         for (int nt = 0; nt < 4; ++nt) {
             const int co = nt * 32 + j;
-            float rx[16];  // residual rows: issue all loads before the MFMA chain needs them
+            const int con = (nt < 3 ? nt + 1 : nt) * 32 + j;
+            float wenxt[16], rxnxt[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) rx[i] = ximg[off[i] + co];
+            for (int k = 0; k < 16; ++k) wenxt[k] = a.we[(2 * k + h) * C + con];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) rxnxt[i] = ximg[off[i] + con];
+            const float s1n = a.es[con], t1n = a.et[con], aln = a.ra[con];
             f32x16 e = {0};
 #pragma unroll
-            for (int s = 0; s < 16; ++s)
-                e = mfma32(qv[ord(s)], a.we[(2 * s + h) * C + co], e);
-            const float s1 = a.es[co], t1 = a.et[co], al = a.ra[co];
+            for (int s = 0; s < 16; ++s) e = mfma32(qv[ord(s)], wecur[s], e);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float v = prelu1(fmaf(e[i], s1, t1) + rx[i], al);
+                const float v = prelu1(fmaf(e[i], s1, t1) + rxcur[i], al);
                 if ((okmask >> i) & 1u) yimg[off[i] + co] = v;
             }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { wecur[k] = wenxt[k]; rxcur[k] = rxnxt[k]; }
+            s1 = s1n; t1 = t1n; al = aln;
         }
     }
+}
+
+struct TileId {
+    int n, py, px, ty0, tx0, Hp, Wp;
+    bool empty;
+};
+
+template <int TW>
+__device__ __forceinline__ TileId decode_tile(const BnkArgs &a)
+{
+    TileId t;
+    const int d = a.dil;
+    int b = blockIdx.x;
+    const int tx = b % a.tiles_x; b /= a.tiles_x;
+    const int ty = b % a.tiles_y; b /= a.tiles_y;
+    t.px = b % d; b /= d;
+    t.py = b % d; b /= d;
+    t.n = b;
+    t.Hp = (a.H - t.py + d - 1) / d;  // rows / cols of this phase sub-image
+    t.Wp = (a.W - t.px + d - 1) / d;
+    t.ty0 = ty * a.TH;
+    t.tx0 = tx * TW;
+    t.empty = (t.ty0 >= t.Hp) || (t.tx0 >= t.Wp);
+    return t;
+}
+
+// regular / dilated 3x3 bottleneck
+template <int TW>
+__global__ __launch_bounds__(256, 2) void k_bottleneck_mfma(BnkArgs a)
+{
+    __shared__ float P[PMAX * PSTR];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const TileId t = decode_tile<TW>(a);
+    if (t.empty) return;  // whole workgroup: no barrier has been reached yet
+    const float *ximg = a.x + (long)t.n * a.H * a.W * C;
+    float *yimg = a.y + (long)t.n * a.H * a.W * C;
+    proj_to_lds<TW, 1>(a, ximg, P, a.TH, t.ty0, t.tx0, t.py, t.px, t.Hp, t.Wp, wave, j, h);
+    __syncthreads();
+    conv_exp_store<TW, 3, 3, TW + 2>(a, ximg, yimg, P, a.wc, a.TH, t.ty0, t.tx0, t.py, t.px, t.Hp,
+                                     t.Wp, wave, j, h);
+}
+
+// asymmetric bottleneck: (5,1) then (1,5) with no BN / activation in between (dilation 1)
+constexpr int PMAX_ASYM = 448;  // >= (8+4)*(32+4) = 432, multiple of 32
+template <int TW>
+__global__ __launch_bounds__(256, 1) void k_bottleneck_mfma_asym(BnkArgs a)
+{
+    __shared__ float P[PMAX_ASYM * PSTR];
+    __shared__ float R[8 * (TW + 4) * PSTR];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const TileId t = decode_tile<TW>(a);
+    if (t.empty) return;
+    const float *ximg = a.x + (long)t.n * a.H * a.W * C;
+    float *yimg = a.y + (long)t.n * a.H * a.W * C;
+    proj_to_lds<TW, 2>(a, ximg, P, a.TH, t.ty0, t.tx0, t.py, t.px, t.Hp, t.Wp, wave, j, h);
+    __syncthreads();
+    conv5x1_to_lds<TW>(a, P, R, a.TH, wave, j, h);
+    __syncthreads();
+    conv_exp_store<TW, 1, 5, TW + 4>(a, ximg, yimg, R, a.wc2, a.TH, t.ty0, t.tx0, t.py, t.px, t.Hp,
+                                     t.Wp, wave, j, h);
 }
 
 // =================================================================================================
@@ -400,20 +509,22 @@ hipError_t launch_probe_swap(float *out, hipStream_t s)
 
 bool bottleneck_mfma_supported(int Cin, int f, bool asym)
 {
-    return !asym && ((Cin == C && f == F) || (Cin == C64 && f == F16));
+    return (Cin == C && f == F) || (!asym && Cin == C64 && f == F16);
 }
 
 hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W, int Cin, int dil,
                                   const float *wp, const float *ps, const float *pt, const float *pa,
-                                  const float *wc, const float *cs, const float *ct, const float *ca,
-                                  const float *we, const float *es, const float *et, const float *ra,
-                                  hipStream_t s)
+                                  const float *wc, const float *wc2, const float *cs, const float *ct,
+                                  const float *ca, const float *we, const float *es, const float *et,
+                                  const float *ra, hipStream_t s)
 {
     if (dil < 1 || dil > 64) return hipErrorInvalidValue;
+    const bool asym = wc2 != nullptr;
+    if (asym && (dil != 1 || Cin != C)) return hipErrorInvalidValue;
     BnkArgs a;
     a.x = x; a.y = y;
     a.wp = wp; a.ps = ps; a.pt = pt; a.pa = pa;
-    a.wc = wc; a.cs = cs; a.ct = ct; a.ca = ca;
+    a.wc = wc; a.wc2 = wc2; a.cs = cs; a.ct = ct; a.ca = ca;
     a.we = we; a.es = es; a.et = et; a.ra = ra;
     a.N = N; a.H = H; a.W = W; a.dil = dil;
     a.TH = 8;
@@ -426,10 +537,16 @@ hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W,
     if (grid <= 0 || grid > 0x7fffffffL) return hipErrorInvalidValue;
     const double pix = (double)N * H * W;
     const double f = Cin / 4.0;
-    ProfScope prof(Cin == C ? "k_bottleneck_mfma" : "k_bottleneck_mfma_f16",
-                   2.0 * pix * (Cin * f + 9.0 * f * f + f * Cin),
-                   4.0 * (2.0 * pix * Cin + Cin * f * 2.0 + 9.0 * f * f), s);
-    if (Cin == C) {
+    const double taps = asym ? 10.0 : 9.0;
+    ProfScope prof(asym ? "k_bottleneck_mfma_asym" : (Cin == C ? "k_bottleneck_mfma" : "k_bottleneck_mfma_f16"),
+                   2.0 * pix * (Cin * f + taps * f * f + f * Cin),
+                   4.0 * (2.0 * pix * Cin + Cin * f * 2.0 + taps * f * f), s);
+    if (asym) {
+        if (wide)
+            hipLaunchKernelGGL(k_bottleneck_mfma_asym<32>, dim3((unsigned)grid), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL(k_bottleneck_mfma_asym<16>, dim3((unsigned)grid), dim3(256), 0, s, a);
+    } else if (Cin == C) {
         if (wide)
             hipLaunchKernelGGL(k_bottleneck_mfma<32>, dim3((unsigned)grid), dim3(256), 0, s, a);
         else

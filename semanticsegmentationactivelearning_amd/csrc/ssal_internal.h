@@ -72,9 +72,9 @@ hipError_t launch_codes_to_argmax(const uint8_t *code, int N, int Ho, int Wo, in
 bool bottleneck_mfma_supported(int Cin, int f, bool asym);
 hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W, int Cin, int dil,
                                   const float *wp, const float *ps, const float *pt, const float *pa,
-                                  const float *wc, const float *cs, const float *ct, const float *ca,
-                                  const float *we, const float *es, const float *et, const float *ra,
-                                  hipStream_t s);
+                                  const float *wc, const float *wc2 /* asym: (1,5) kernel, else NULL */,
+                                  const float *cs, const float *ct, const float *ca, const float *we,
+                                  const float *es, const float *et, const float *ra, hipStream_t s);
 hipError_t launch_probe_swap(float *out, hipStream_t s);
 
 hipError_t launch_prelu(const float *x, int64_t pixels, int C, const float *alpha, float *y,

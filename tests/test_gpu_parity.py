@@ -233,12 +233,14 @@ def test_permlane32_swap_lane_semantics():
     ("Bottleneck3_8", 1, 16, 16), ("Bottleneck2_1", 1, 1, 1),
     ("Bottleneck1_1", 2, 16, 32), ("Bottleneck1_3", 1, 9, 11), ("Bottleneck1_4", 1, 24, 72), ("Bottleneck4_1", 2, 32, 64),
     ("Bottleneck4_2", 1, 1, 1), ("Bottleneck1_2", 1, 8, 40),
+    ("Bottleneck2_3", 2, 16, 32), ("Bottleneck2_7", 1, 9, 11), ("Bottleneck3_3", 1, 24, 72), ("Bottleneck3_7", 2, 32, 64),
+    ("Bottleneck2_3", 1, 1, 1), ("Bottleneck3_7", 1, 8, 40), ("Bottleneck2_7", 1, 5, 3),
 ])
 def test_mfma_bottleneck_equals_generic_and_oracle(enet_c3k19, name, n, h, w):
     net, P = enet_c3k19
     layer = getattr(net, name)
     x = np.random.default_rng(18).normal(size=(n, h, w, layer.output_channels)).astype(np.float32)
-    want = orc.bottleneck(P, name, x, dil=layer.dilation_rate[0], asym=False)
+    want = orc.bottleneck(P, name, x, dil=layer.dilation_rate[0], asym=layer.asymmetric)
     xd = dev(x)
     try:
         _lib.set_kernel_family(True)

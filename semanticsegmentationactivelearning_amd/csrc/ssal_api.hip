@@ -114,6 +114,7 @@ struct DevLayer {
     const float *conv_scale = nullptr, *conv_shift = nullptr, *conv_alpha = nullptr;
     const float *exp_w = nullptr, *exp_scale = nullptr, *exp_shift = nullptr;
     const float *res_w = nullptr, *res_alpha = nullptr;
+    const float *convT_stacked = nullptr;  // Upsample: [6][f][2*cf] parity-stacked transposed-conv kernel
 };
 
 struct ssal_enet {
@@ -299,6 +300,28 @@ void fold_bn(const ssal_enet *h, const std::string &prefix, int c, std::vector<f
     }
 }
 
+// Parity-stacked transposed-conv kernel for the MFMA upsample kernel: ws[slot][ci][row], rows
+// [0,O) = first class, [O,2O) = second class of the slot (zeros where the class has no tap):
+//   slot 0: P(i,j)     [W00 | W01]     slot 1: P(i,j-1)   [W02 | 0]
+//   slot 2: P(i-1,j)   [W20 | W21]     slot 3: P(i-1,j-1) [W22 | 0]
+//   slot 4: P(i,j)     [W10 | W11]     slot 5: P(i,j-1)   [W12 | 0]
+// with Wab[ci][co] = kernel[a][b][co][ci] (TF HW-O-I layout).
+std::vector<float> stack_convT(const std::vector<float> &w, int O, int I)
+{
+    static const int taps[6][2] = {{0, 1}, {2, -1}, {6, 7}, {8, -1}, {3, 4}, {5, -1}};  // kh*3+kw
+    const int R = 2 * O;
+    std::vector<float> r((size_t)6 * I * R, 0.0f);
+    for (int sl = 0; sl < 6; ++sl)
+        for (int half = 0; half < 2; ++half) {
+            const int t = taps[sl][half];
+            if (t < 0) continue;
+            for (int ci = 0; ci < I; ++ci)
+                for (int co = 0; co < O; ++co)
+                    r[((size_t)sl * I + ci) * R + half * O + co] = w[((size_t)t * O + co) * I + ci];
+        }
+    return r;
+}
+
 // [3,3,O,I] (TF conv2d_transpose kernel) -> [3][3][I][O]
 std::vector<float> hwoi_to_hwio(const std::vector<float> &w, int O, int I)
 {
@@ -373,6 +396,7 @@ SSAL_API int ssal_enet_commit(ssal_enet *net, void *stream)
             o.v[11] = ab.push(t);
             o.v[12] = sp.kind == K_UP ? ab.push(T(net, n + "res_kernel")) : 0;
             o.v[13] = ab.push(T(net, n + "residual_alpha"));
+            o.v[14] = sp.kind == K_UP ? ab.push(stack_convT(T(net, n + "conv_kernel"), cf, f)) : 0;
             break;
         }
         case K_FINAL:
@@ -415,6 +439,7 @@ SSAL_API int ssal_enet_commit(ssal_enet *net, void *stream)
             L.exp_w = A + o.v[9]; L.exp_scale = A + o.v[10]; L.exp_shift = A + o.v[11];
             L.res_w = L.kind == K_UP ? A + o.v[12] : nullptr;
             L.res_alpha = A + o.v[13];
+            L.convT_stacked = L.kind == K_UP ? A + o.v[14] : nullptr;
             break;
         }
     }
@@ -554,6 +579,11 @@ hipError_t run_up(const DevLayer &L, const float *x, int n, int h, int w, float 
                   const uint8_t *code, const int64_t *argmax, const LayerTemps &T, hipStream_t s)
 {
     const int C = L.cin, pf = L.f, cf = L.cf;
+    if (g_use_mfma && code && (long)h * w * 4 * L.cout < (1L << 31) && upsample_mfma_supported(C, L.cout))
+        return launch_upsample_mfma(x, y, code, n, h, w, L.proj_w, L.proj_scale, L.proj_shift,
+                                    L.proj_alpha, L.convT_stacked, L.conv_scale, L.conv_shift,
+                                    L.conv_alpha, L.exp_w, L.exp_scale, L.exp_shift, L.res_w,
+                                    L.res_alpha, s);
     ConvArgs p = conv_args(x, n, h, w, C, L.proj_w, 1, 1, pf, 1, 1, T.t0);
     p.scale = L.proj_scale; p.shift = L.proj_shift; p.alpha = L.proj_alpha;
     HIP_RET(launch_conv(p, s));
@@ -749,6 +779,7 @@ SSAL_API int64_t ssal_enet_layer_workspace_bytes(const ssal_enet *net, const cha
     int64_t bytes = 1024;
     for (int k = 0; k < 4; ++k) bytes += sz[k] * 4 + 256;
     if (L.kind == K_DOWN) bytes += (int64_t)n * (h / 2) * (w / 2) * L.cin + 256;
+    if (L.kind == K_UP) bytes += (int64_t)n * h * w * L.cout + 1024;
     if (L.kind == K_FINAL) bytes += (int64_t)n * final_score_blocks(h, w) * 8 + 256;
     return bytes;
 }
@@ -794,10 +825,22 @@ SSAL_API int ssal_enet_run_layer(ssal_enet *net, const char *layer, const float 
             HIP_TRY(launch_codes_to_argmax(code, n, h / 2, w / 2, L.cin, argmax_out_dev, s));
         break;
     }
-    case K_UP:
+    case K_UP: {
         if (!argmax_in_dev) return fail(SSAL_EINVAL, "layer '%s' needs argmax_in_dev", layer);
-        HIP_TRY(run_up(L, x_dev, n, h, w, y_dev, nullptr, argmax_in_dev, T, s));
+        // indices produced by a 2x2/s2 pooling always lie in their own window: then the 1-byte window
+        // code form (gather unpool, fused kernels) is exact; arbitrary indices take the scatter form
+        uint8_t *code = b.take<uint8_t>((int64_t)n * h * w * L.cout);
+        int *bad = b.take<int>(1);
+        HIP_TRY(launch_argmax_to_codes(argmax_in_dev, n, h, w, L.cout, code, bad, s));
+        int bad_host = 0;
+        HIP_TRY(hipMemcpyAsync(&bad_host, bad, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (bad_host == 0)
+            HIP_TRY(run_up(L, x_dev, n, h, w, y_dev, code, nullptr, T, s));
+        else
+            HIP_TRY(run_up(L, x_dev, n, h, w, y_dev, nullptr, argmax_in_dev, T, s));
         break;
+    }
     case K_FINAL: {
         double *partial = b.take<double>((int64_t)n * final_score_blocks(h, w));
         HIP_TRY(launch_final_score(x_dev, n, h, w, L.w, net->classes, y_dev,

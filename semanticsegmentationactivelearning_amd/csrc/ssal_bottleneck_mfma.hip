@@ -68,8 +68,8 @@ __device__ __host__ constexpr int ord(int s) { return (s & ~3) | ((s & 1) << 1) 
 // ---- phase A (shared by the regular and the asymmetric kernel): 1x1 projection + BN + PReLU of the
 // halo'd tile into LDS; pixels outside the image are written as exact zeros (SAME padding of the
 // following conv applies to the PROJECTED tensor).  HALO = 1 (3x3) or 2 (5x1 / 1x5).
-template <int TW, int HALO>
-__device__ __forceinline__ void proj_to_lds(const BnkArgs &a, const float *ximg, float *P, int TH,
+template <int TW, int HALO, typename Args>
+__device__ __forceinline__ void proj_to_lds(const Args &a, const float *ximg, float *P, int TH,
                                             int ty0, int tx0, int py, int px, int Hp, int Wp,
                                             int wave, int j, int h)
 {
@@ -323,6 +323,181 @@ __global__ __launch_bounds__(256, 1) void k_bottleneck_mfma_asym(BnkArgs a)
 }
 
 // =================================================================================================
+// Upsample bottleneck, C = 128 -> 64 (Bottleneck4_0; enet_modules.py:1217-1292) in one launch:
+//   main:     1x1 proj (128 -> 32) + BN + PReLU  ->  conv2d_transpose 3x3/s2 (32 -> 16) + BN + PReLU
+//             -> 1x1 exp (16 -> 64) + BN
+//   residual: 1x1 conv (128 -> 64, no BN) -> unpool_2d with the saved 2x2 window codes (gather form)
+//   out = PReLU(main + residual)                                       [N,H,W,128] -> [N,2H,2W,64]
+// The transposed conv is evaluated per OUTPUT PARITY class of an input pixel (i,j):
+//   ee out(2i,2j)     = P(i,j)W00 + P(i,j-1)W02 + P(i-1,j)W20 + P(i-1,j-1)W22
+//   eo out(2i,2j+1)   = P(i,j)W01 + P(i-1,j)W21
+//   oe out(2i+1,2j)   = P(i,j)W10 + P(i,j-1)W12
+//   oo out(2i+1,2j+1) = P(i,j)W11                    (taps in (kh,kw) ascending = oracle order)
+// With only 16 output channels two classes share one 32-row MFMA: accumulator A carries
+// [ee | eo], accumulator B carries [oe | oo]; the commit step stacks the kernels accordingly
+// (ws[slot][ci][row], zero rows where a class has no tap: adding an exact zero keeps the chain).
+// =================================================================================================
+struct UpArgs {
+    const float *x;
+    float *y;
+    const uint8_t *code;             // [N,H,W,64] window codes dy*2+dx saved by the matching downsample
+    const float *wp, *ps, *pt, *pa;  // proj kernel [128][32], folded BN, alpha
+    const float *ws;                 // stacked transposed-conv kernel [6][32][32]
+    const float *cs, *ct, *ca;       // [16]
+    const float *we, *es, *et;       // exp kernel [16][64], folded BN [64]
+    const float *wr;                 // residual kernel [128][64]
+    const float *ra;                 // [64]
+    int N, H, W, dil;                // dil == 1
+    int TH, tiles_y, tiles_x;
+};
+
+constexpr int CUP = 64;  // output channels of the upsample block
+
+template <int TW>
+__global__ __launch_bounds__(256, 2) void k_upsample_mfma(UpArgs a)
+{
+    __shared__ float P[PMAX * PSTR];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    constexpr int HW2 = TW + 2;
+    int b = blockIdx.x;
+    const int tx = b % a.tiles_x; b /= a.tiles_x;
+    const int ty = b % a.tiles_y; b /= a.tiles_y;
+    const int n = b;
+    const int TH = a.TH;
+    const int ty0 = ty * TH, tx0 = tx * TW;
+    const float *ximg = a.x + (long)n * a.H * a.W * C;
+    const uint8_t *cimg = a.code + (long)n * a.H * a.W * CUP;
+    float *yimg = a.y + (long)n * 4 * a.H * a.W * CUP;
+
+    proj_to_lds<TW, 1>(a, ximg, P, TH, ty0, tx0, 0, 0, a.H, a.W, wave, j, h);
+    __syncthreads();
+
+    const int nmt = (TH * TW) / 32;
+    for (int mt = wave; mt < nmt; mt += 4) {
+        const int t = mt * 32 + j;
+        const int r = t / TW, c = t - r * TW;
+        const bool lane_ok = (ty0 + r < a.H) && (tx0 + c < a.W);
+
+        // ---- residual branch: D[pixel][co] = X[pixel][ci] * Wr[ci][co], two N-tiles of 32 --------
+        f32x16 res0 = {0}, res1 = {0};
+        {
+            const float *xp = lane_ok ? ximg + ((long)(ty0 + r) * a.W + (tx0 + c)) * C : ximg;
+#pragma unroll 1
+            for (int kc = 0; kc < 4; ++kc) {
+                float4 v[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    v[m] = *reinterpret_cast<const float4 *>(xp + kc * 32 + (2 * m + h) * 4);
+                float w0[16], w1[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    w0[k] = a.wr[(kc * 32 + 2 * k + h) * CUP + j];
+                    w1[k] = a.wr[(kc * 32 + 2 * k + h) * CUP + 32 + j];
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    float a0 = v[m].x, a1 = v[m].y, a2 = v[m].z, a3 = v[m].w;
+                    swap32(a0, a1);
+                    swap32(a2, a3);
+                    res0 = mfma32(a0, w0[4 * m + 0], res0); res1 = mfma32(a0, w1[4 * m + 0], res1);
+                    res0 = mfma32(a2, w0[4 * m + 1], res0); res1 = mfma32(a2, w1[4 * m + 1], res1);
+                    res0 = mfma32(a1, w0[4 * m + 2], res0); res1 = mfma32(a1, w1[4 * m + 2], res1);
+                    res0 = mfma32(a3, w0[4 * m + 3], res0); res1 = mfma32(a3, w1[4 * m + 3], res1);
+                }
+            }
+        }
+
+        // ---- transposed conv: two stacked accumulators ------------------------------------------
+        f32x16 accA = {0}, accB = {0};
+#pragma unroll 1
+        for (int slot = 0; slot < 4; ++slot) {  // P(i,j), P(i,j-1), P(i-1,j), P(i-1,j-1)
+            const int dr = 1 - (slot >> 1), dc = 1 - (slot & 1);
+            const float *pq = P + ((r + dr) * HW2 + (c + dc)) * PSTR + 2 * h;
+            const float *wt = a.ws + (slot * F + h) * 32 + j;
+#pragma unroll
+            for (int sq = 0; sq < 8; ++sq) {
+                float2 pv = *reinterpret_cast<const float2 *>(pq + 4 * sq);
+                float b0 = pv.x, b1 = pv.y;
+                swap32(b0, b1);
+                accA = mfma32(wt[(4 * sq) * 32], b0, accA);
+                accA = mfma32(wt[(4 * sq + 2) * 32], b1, accA);
+            }
+        }
+#pragma unroll 1
+        for (int slot = 4; slot < 6; ++slot) {  // P(i,j), P(i,j-1)
+            const int dc = 1 - (slot & 1);
+            const float *pq = P + ((r + 1) * HW2 + (c + dc)) * PSTR + 2 * h;
+            const float *wt = a.ws + (slot * F + h) * 32 + j;
+#pragma unroll
+            for (int sq = 0; sq < 8; ++sq) {
+                float2 pv = *reinterpret_cast<const float2 *>(pq + 4 * sq);
+                float b0 = pv.x, b1 = pv.y;
+                swap32(b0, b1);
+                accB = mfma32(wt[(4 * sq) * 32], b0, accB);
+                accB = mfma32(wt[(4 * sq + 2) * 32], b1, accB);
+            }
+        }
+        // BN + PReLU; reg i: class = i >> 3, channel = (i&3) + 8*((i>>2)&1) + 4h
+        float qa[16], qb[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int co = (i & 3) + 8 * ((i >> 2) & 1) + 4 * h;
+            const float sc = a.cs[co], sh = a.ct[co], al = a.ca[co];
+            qa[i] = prelu1(fmaf(accA[i], sc, sh), al);
+            qb[i] = prelu1(fmaf(accB[i], sc, sh), al);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            swap32(qa[2 * u], qa[2 * u + 1]);
+            swap32(qb[2 * u], qb[2 * u + 1]);
+        }
+
+        // ---- expansion (16 -> 64) per parity class + BN + gather-unpool residual + PReLU ----------
+        int ooff[16], coff[16];
+        unsigned okmask = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ti = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const int rr = ti / TW, cc = ti - rr * TW;
+            const int iy = ty0 + rr, ix = tx0 + cc;
+            const bool ok = (iy < a.H) && (ix < a.W);
+            okmask |= ok ? (1u << i) : 0u;
+            coff[i] = ok ? (iy * a.W + ix) * CUP : 0;
+            ooff[i] = ok ? ((2 * iy) * (2 * a.W) + 2 * ix) * CUP : 0;
+        }
+#pragma unroll 1
+        for (int nt = 0; nt < 2; ++nt) {
+            const int co = nt * 32 + j;
+            float wef[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) wef[s] = a.we[(2 * s + h) * CUP + co];
+            int cd[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) cd[i] = cimg[coff[i] + co];
+            const float s1 = a.es[co], t1 = a.et[co], al = a.ra[co];
+#pragma unroll
+            for (int cls = 0; cls < 4; ++cls) {  // ee, eo, oe, oo  (== window code dy*2+dx)
+                f32x16 e = {0};
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const float av = (cls < 2) ? qa[(cls & 1) * 8 + ord(s)] : qb[(cls & 1) * 8 + ord(s)];
+                    e = mfma32(av, wef[s], e);
+                }
+                const int shift = ((cls >> 1) * (2 * a.W) + (cls & 1)) * CUP;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float rs = nt == 0 ? res0[i] : res1[i];
+                    const float rsd = (cd[i] == cls) ? rs : 0.0f;
+                    const float v = prelu1(fmaf(e[i], s1, t1) + rsd, al);
+                    if ((okmask >> i) & 1u) yimg[ooff[i] + shift + co] = v;
+                }
+            }
+        }
+    }
+}
+
+// =================================================================================================
 // C = 64 / F = 16 variant (stage 1 and stage 4 bottlenecks) on v_mfma_f32_16x16x4_f32.
 // lane maps (l = lane, i = l & 15, g = l >> 4):  A: A[row i][k = g]   B: B[k = g][col i]
 //   D: reg r holds D[row 4*g + r][col i].  One instruction consumes k = 0,1,2,3 (lane quarters) in
@@ -504,6 +679,38 @@ __global__ void k_probe_swap(float *out)
 hipError_t launch_probe_swap(float *out, hipStream_t s)
 {
     hipLaunchKernelGGL(k_probe_swap, dim3(1), dim3(64), 0, s, out);
+    return hipGetLastError();
+}
+
+bool upsample_mfma_supported(int Cin, int Cout) { return Cin == C && Cout == CUP; }
+
+hipError_t launch_upsample_mfma(const float *x, float *y, const uint8_t *code, int N, int H, int W,
+                                const float *wp, const float *ps, const float *pt, const float *pa,
+                                const float *ws, const float *cs, const float *ct, const float *ca,
+                                const float *we, const float *es, const float *et, const float *wr,
+                                const float *ra, hipStream_t s)
+{
+    UpArgs a;
+    a.x = x; a.y = y; a.code = code;
+    a.wp = wp; a.ps = ps; a.pt = pt; a.pa = pa;
+    a.ws = ws; a.cs = cs; a.ct = ct; a.ca = ca;
+    a.we = we; a.es = es; a.et = et; a.wr = wr; a.ra = ra;
+    a.N = N; a.H = H; a.W = W; a.dil = 1;
+    a.TH = 8;
+    const bool wide = W > 16;
+    const int TW = wide ? 32 : 16;
+    a.tiles_y = (H + a.TH - 1) / a.TH;
+    a.tiles_x = (W + TW - 1) / TW;
+    const long grid = (long)N * a.tiles_y * a.tiles_x;
+    if (grid <= 0 || grid > 0x7fffffffL) return hipErrorInvalidValue;
+    const double pix = (double)N * H * W;
+    ProfScope prof("k_upsample_mfma",
+                   2.0 * pix * (C * 32.0 + 9.0 * 32 * 16 + 4.0 * 16 * CUP + C * (double)CUP),
+                   4.0 * (pix * C + 4.0 * pix * CUP) + pix * CUP, s);
+    if (wide)
+        hipLaunchKernelGGL(k_upsample_mfma<32>, dim3((unsigned)grid), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_upsample_mfma<16>, dim3((unsigned)grid), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

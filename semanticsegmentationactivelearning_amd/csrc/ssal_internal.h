@@ -65,6 +65,8 @@ hipError_t launch_maxpool_argmax(const float *x, int N, int H, int W, int C, flo
                                  int64_t *argmax, int include_batch, hipStream_t s);
 hipError_t launch_unpool_scatter(const float *x, const int64_t *idx, int N, int H, int W, int C,
                                  int idx_has_batch, float *y, hipStream_t s);
+hipError_t launch_argmax_to_codes(const int64_t *argmax, int N, int Ho, int Wo, int C, uint8_t *code,
+                                  int *bad, hipStream_t s);
 hipError_t launch_codes_to_argmax(const uint8_t *code, int N, int Ho, int Wo, int C,
                                   int64_t *argmax, hipStream_t s);
 
@@ -75,6 +77,13 @@ hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W,
                                   const float *wc, const float *wc2 /* asym: (1,5) kernel, else NULL */,
                                   const float *cs, const float *ct, const float *ca, const float *we,
                                   const float *es, const float *et, const float *ra, hipStream_t s);
+// MFMA-fused upsample bottleneck 128 -> 64 (window-code unpooling); ws = stacked transposed-conv kernel
+bool upsample_mfma_supported(int Cin, int Cout);
+hipError_t launch_upsample_mfma(const float *x, float *y, const uint8_t *code, int N, int H, int W,
+                                const float *wp, const float *ps, const float *pt, const float *pa,
+                                const float *ws, const float *cs, const float *ct, const float *ca,
+                                const float *we, const float *es, const float *et, const float *wr,
+                                const float *ra, hipStream_t s);
 hipError_t launch_probe_swap(float *out, hipStream_t s);
 
 hipError_t launch_prelu(const float *x, int64_t pixels, int C, const float *alpha, float *y,

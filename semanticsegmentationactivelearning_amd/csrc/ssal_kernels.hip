@@ -664,6 +664,43 @@ hipError_t launch_codes_to_argmax(const uint8_t *code, int N, int Ho, int Wo, in
     return hipGetLastError();
 }
 
+// reference int64 index -> window code; *bad is set if an index does not lie inside its own 2x2 window
+// (then the caller must fall back to the scatter form of unpool_2d)
+__global__ __launch_bounds__(256) void k_argmax_to_codes(const int64_t *__restrict__ argmax, int N,
+                                                         int Ho, int Wo, int C,
+                                                         uint8_t *__restrict__ code,
+                                                         int *__restrict__ bad)
+{
+    const long total = (long)N * Ho * Wo * C;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
+        const int c = (int)(o % C);
+        const long pix = o / C;
+        const int ox = (int)(pix % Wo);
+        const int oy = (int)((pix / Wo) % Ho);
+        const long idx = argmax[o];
+        int found = -1;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const long cand = ((long)(2 * oy + (d >> 1)) * (2 * Wo) + (2 * ox + (d & 1))) * C + c;
+            if (idx == cand) found = d;
+        }
+        if (found < 0) { atomicOr(bad, 1); found = 0; }
+        code[o] = (uint8_t)found;
+    }
+}
+
+hipError_t launch_argmax_to_codes(const int64_t *argmax, int N, int Ho, int Wo, int C, uint8_t *code,
+                                  int *bad, hipStream_t s)
+{
+    const long total = (long)N * Ho * Wo * C;
+    int grid = cdiv(total, 256);
+    if (grid > 65536) grid = 65536;
+    hipError_t e = hipMemsetAsync(bad, 0, sizeof(int), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_argmax_to_codes, dim3(grid), dim3(256), 0, s, argmax, N, Ho, Wo, C, code, bad);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // Elementwise operators of models/util/extra_ops.py exposed through the C ABI.
 // ------------------------------------------------------------------------------------------------

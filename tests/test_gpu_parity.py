@@ -253,6 +253,30 @@ def test_mfma_bottleneck_equals_generic_and_oracle(enet_c3k19, name, n, h, w):
     report_diff(name + " MFMA vs oracle (bit-exact)", got_mfma, want)
 
 
+@pytest.mark.parametrize("name,n,h,w", [("Bottleneck4_0", 2, 16, 32), ("Bottleneck4_0", 1, 9, 11), ("Bottleneck4_0", 1, 8, 40),
+                                        ("Bottleneck4_0", 1, 1, 1), ("Bottleneck5_0", 2, 16, 32), ("Bottleneck5_0", 1, 7, 5)])
+def test_upsample_layer_both_unpool_forms_and_families(enet_c3k19, name, n, h, w):
+    """pooling-derived indices take the window-code (gather) form, arbitrary indices the scatter form"""
+    net, P = enet_c3k19
+    layer = getattr(net, name)
+    cin, cout = layer.proj_kernel.shape[2], layer.output_channels
+    rng = np.random.default_rng(19)
+    x = rng.normal(size=(n, h, w, cin)).astype(np.float32)
+    _, arg_pool = orc.maxpool2x2_argmax(rng.normal(size=(n, 2 * h, 2 * w, cout)).astype(np.float32))
+    # arbitrary (but unique per image) indices: a random permutation of the output positions
+    arg_any = np.stack([rng.permutation(4 * h * w * cout)[: h * w * cout].reshape(h, w, cout) for _ in range(n)])
+    xd = dev(x)
+    for arg in (arg_pool, arg_any):
+        want = orc.bottleneck_up(P, name, x, arg)
+        try:
+            for fam in (True, False):
+                _lib.set_kernel_family(fam)
+                got = layer(xd, dev(arg), training=False).cpu().numpy()
+                report_diff("%s family=%s" % (name, "mfma" if fam else "generic"), got, want)
+        finally:
+            _lib.set_kernel_family(True)
+
+
 # ---- whole network -------------------------------------------------------------------------------
 def _check_forward(net, P, x, tag):
     ep = {}

@@ -561,6 +561,10 @@ hipError_t run_down(const DevLayer &L, const float *x, int n, int h, int w, floa
                     const LayerTemps &T, hipStream_t s)
 {
     const int C = L.cin, f = L.f;
+    if (g_use_mfma && (long)h * w * L.cout < (1L << 31) && downsample_mfma_supported(C, L.cout))
+        return launch_downsample_mfma(x, y, code, n, h, w, L.proj_w, L.proj_scale, L.proj_shift,
+                                      L.proj_alpha, L.conv_w, L.conv_scale, L.conv_shift, L.conv_alpha,
+                                      L.exp_w, L.exp_scale, L.exp_shift, L.res_alpha, s);
     ConvArgs p = conv_args(x, n, h, w, C, L.proj_w, 2, 2, f, 2, 1, T.t0);
     p.scale = L.proj_scale; p.shift = L.proj_shift; p.alpha = L.proj_alpha;
     HIP_RET(launch_conv(p, s));

@@ -160,8 +160,59 @@ __device__ __forceinline__ void conv5x1_to_lds(const BnkArgs &a, const float *P,
     }
 }
 
-// ---- last phase: KH x KW conv over an LDS tensor S (row stride SW pixels) + BN + PReLU, then the
-// 1x1 expansion + BN + residual + PReLU straight to HBM.
+// ---- KH x KW conv (F -> F) over an LDS tensor S (row stride SW pixels) for one 32-pixel M-tile,
+// + BN + PReLU; returns the result as the A operand of the following expansion GEMM:
+// qv[ord(s)] of lane (pixel j, half h) = Q[pixel][ci = 2s + h].
+template <int TW, int KH, int KW, int SW, typename Args>
+__device__ __forceinline__ void conv_tile_q(const Args &a, const float *S, const float *wconv, int mt,
+                                            int j, int h, float (&qv)[16])
+{
+    const int t = mt * 32 + j;  // this lane's output pixel inside the tile (B operand)
+    const int r = t / TW, c = t - r * TW;
+    f32x16 acc = {0};
+    // software pipeline: the 16 weight fragments of tap t+1 are requested before the 16 MFMAs of
+    // tap t are issued, so their L2 latency hides behind ~1000 cycles of matrix work
+    float wcur[16];
+    {
+        const float *wt = wconv + (long)h * F + j;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) wcur[k] = wt[(2 * k) * F];  // W[0][ci = 2k + h][co = j]
+    }
+#pragma unroll 1
+    for (int tap = 0; tap < KH * KW; ++tap) {
+        const int kh = tap / KW, kw = tap - KW * kh;
+        const int tn = tap + 1 < KH * KW ? tap + 1 : tap;
+        float wnxt[16];
+        {
+            const float *wt = wconv + (long)(tn * F + h) * F + j;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) wnxt[k] = wt[(2 * k) * F];
+        }
+        const float *pq = S + ((r + kh) * SW + (c + kw)) * PSTR + 2 * h;
+#pragma unroll
+        for (int sq = 0; sq < 8; ++sq) {
+            float2 pv = *reinterpret_cast<const float2 *>(pq + 4 * sq);
+            float b0 = pv.x, b1 = pv.y;
+            swap32(b0, b1);  // b0 = ci(4sq | 4sq+1), b1 = ci(4sq+2 | 4sq+3)
+            acc = mfma32(wcur[2 * sq], b0, acc);      // W[tap][ci = 4sq + h][co = j]
+            acc = mfma32(wcur[2 * sq + 1], b1, acc);  // W[tap][ci = 4sq + 2 + h][co = j]
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) wcur[k] = wnxt[k];
+    }
+    // conv epilogue: rows = co (registers), cols = pixel (lanes)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int co = (i & 3) + 8 * (i >> 2) + 4 * h;
+        qv[i] = prelu1(fmaf(acc[i], a.cs[co], a.ct[co]), a.ca[co]);
+    }
+    // the accumulator tile becomes the A operand of the expansion GEMM (lane = pixel)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) swap32(qv[2 * u], qv[2 * u + 1]);
+}
+
+// ---- last phase of the regular / asymmetric bottleneck: conv, then 1x1 expansion + BN + identity
+// residual + PReLU straight to HBM.
 template <int TW, int KH, int KW, int SW>
 __device__ __forceinline__ void conv_exp_store(const BnkArgs &a, const float *ximg, float *yimg,
                                                const float *S, const float *wconv, int TH, int ty0,
@@ -171,49 +222,8 @@ __device__ __forceinline__ void conv_exp_store(const BnkArgs &a, const float *xi
     const int d = a.dil;
     const int nmt_out = (TH * TW) / 32;
     for (int mt = wave; mt < nmt_out; mt += 4) {
-        const int t = mt * 32 + j;  // this lane's output pixel inside the tile (B operand)
-        const int r = t / TW, c = t - r * TW;
-        f32x16 acc = {0};
-        // software pipeline: the 16 weight fragments of tap t+1 are requested before the 16 MFMAs of
-        // tap t are issued, so their L2 latency hides behind ~1000 cycles of matrix work
-        float wcur[16];
-        {
-            const float *wt = wconv + (long)h * F + j;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) wcur[k] = wt[(2 * k) * F];  // W[0][ci = 2k + h][co = j]
-        }
-#pragma unroll 1
-        for (int tap = 0; tap < KH * KW; ++tap) {
-            const int kh = tap / KW, kw = tap - KW * kh;
-            const int tn = tap + 1 < KH * KW ? tap + 1 : tap;
-            float wnxt[16];
-            {
-                const float *wt = wconv + (long)(tn * F + h) * F + j;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) wnxt[k] = wt[(2 * k) * F];
-            }
-            const float *pq = S + ((r + kh) * SW + (c + kw)) * PSTR + 2 * h;
-#pragma unroll
-            for (int sq = 0; sq < 8; ++sq) {
-                float2 pv = *reinterpret_cast<const float2 *>(pq + 4 * sq);
-                float b0 = pv.x, b1 = pv.y;
-                swap32(b0, b1);  // b0 = ci(4sq | 4sq+1), b1 = ci(4sq+2 | 4sq+3)
-                acc = mfma32(wcur[2 * sq], b0, acc);      // W[tap][ci = 4sq + h][co = j]
-                acc = mfma32(wcur[2 * sq + 1], b1, acc);  // W[tap][ci = 4sq + 2 + h][co = j]
-            }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) wcur[k] = wnxt[k];
-        }
-        // conv epilogue: rows = co (registers), cols = pixel (lanes)
         float qv[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int co = (i & 3) + 8 * (i >> 2) + 4 * h;
-            qv[i] = prelu1(fmaf(acc[i], a.cs[co], a.ct[co]), a.ca[co]);
-        }
-        // the accumulator tile becomes the A operand of the expansion GEMM (lane = pixel)
-#pragma unroll
-        for (int u = 0; u < 8; ++u) swap32(qv[2 * u], qv[2 * u + 1]);
+        conv_tile_q<TW, KH, KW, SW>(a, S, wconv, mt, j, h, qv);
 
         // element offsets (inside image n) of the 16 output rows this lane-half stores
         int off[16];
@@ -320,6 +330,154 @@ __global__ __launch_bounds__(256, 1) void k_bottleneck_mfma_asym(BnkArgs a)
     __syncthreads();
     conv_exp_store<TW, 1, 5, TW + 4>(a, ximg, yimg, R, a.wc2, a.TH, t.ty0, t.tx0, t.py, t.px, t.Hp,
                                      t.Wp, wave, j, h);
+}
+
+// =================================================================================================
+// Downsample bottleneck, C = 64 -> 128 (Bottleneck2_0; enet_modules.py:868-938) in one launch:
+//   main:     2x2/s2 proj (64 -> 32) + BN + PReLU -> 3x3 conv (32 -> 32) + BN + PReLU -> 1x1 exp
+//             (32 -> 128) + BN
+//   residual: max_pool_with_argmax 2x2/s2 of the block input, zero-padded to 128 channels; the first
+//             maximum in (dy,dx) order wins; its window code dy*2+dx is saved for the upsample block
+//   out = PReLU(main + residual)                                   [N,H,W,64] -> [N,H/2,W/2,128]
+// The strided projection is a GEMM with K = (dy,dx,ci) = 4 x 64 over the 2x2 input patch of every
+// (halo'd) output pixel.
+// =================================================================================================
+struct DownArgs {
+    const float *x;                  // [N,H,W,64]
+    float *y;                        // [N,H/2,W/2,128]
+    uint8_t *code;                   // [N,H/2,W/2,64]
+    const float *wp, *ps, *pt, *pa;  // proj kernel [2][2][64][32], folded BN, alpha
+    const float *wc, *cs, *ct, *ca;  // conv kernel [3][3][32][32]
+    const float *we, *es, *et, *ra;  // exp kernel [32][128]
+    int N, H, W;                     // INPUT dims (even)
+    int TH, tiles_y, tiles_x;
+};
+
+constexpr int CDN = 64;  // input channels of the downsample block
+
+template <int TW>
+__global__ __launch_bounds__(256, 2) void k_downsample_mfma(DownArgs a)
+{
+    __shared__ float P[PMAX * PSTR];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    constexpr int HW2 = TW + 2;
+    const int Ho = a.H / 2, Wo = a.W / 2;
+    int b = blockIdx.x;
+    const int tx = b % a.tiles_x; b /= a.tiles_x;
+    const int ty = b % a.tiles_y; b /= a.tiles_y;
+    const int n = b;
+    const int TH = a.TH;
+    const int ty0 = ty * TH, tx0 = tx * TW;
+    const float *ximg = a.x + (long)n * a.H * a.W * CDN;
+    float *yimg = a.y + (long)n * Ho * Wo * C;
+    uint8_t *cimg = a.code + (long)n * Ho * Wo * CDN;
+
+    // ---- phase A: 2x2/s2 projection of the halo'd output tile -> LDS ----------------------------
+    {
+        const float bs = a.ps[j], bt = a.pt[j], ba = a.pa[j];
+        const int npix_halo = (TH + 2) * HW2;
+        const int nmt = (npix_halo + 31) / 32;
+        for (int mt = wave; mt < nmt; mt += 4) {
+            const int q = mt * 32 + j;
+            const int hr = q / HW2, hc = q - hr * HW2;
+            const int pr = ty0 - 1 + hr, pc = tx0 - 1 + hc;
+            const bool valid = (q < npix_halo) && (pr >= 0) && (pr < Ho) && (pc >= 0) && (pc < Wo);
+            const unsigned long long vmask = __ballot(valid);
+            if (vmask == 0ull) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int qi = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    P[qi * PSTR + j] = 0.0f;
+                }
+                continue;
+            }
+            const float *xp = valid ? ximg + ((long)(2 * pr) * a.W + 2 * pc) * CDN : ximg;
+            f32x16 acc = {0};
+#pragma unroll 1
+            for (int tap = 0; tap < 4; ++tap) {  // (dy,dx) ascending == (kh,kw) order of the oracle
+                const float *xt = xp + ((tap >> 1) * a.W + (tap & 1)) * CDN;
+                float4 v[8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+                    v[m] = *reinterpret_cast<const float4 *>(xt + (2 * m + h) * 4);
+                float wf[32];
+#pragma unroll
+                for (int k = 0; k < 32; ++k) wf[k] = a.wp[(tap * CDN + 2 * k + h) * F + j];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    float a0 = v[m].x, a1 = v[m].y, a2 = v[m].z, a3 = v[m].w;
+                    swap32(a0, a1);
+                    swap32(a2, a3);
+                    acc = mfma32(a0, wf[4 * m + 0], acc);
+                    acc = mfma32(a2, wf[4 * m + 1], acc);
+                    acc = mfma32(a1, wf[4 * m + 2], acc);
+                    acc = mfma32(a3, wf[4 * m + 3], acc);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ri = (i & 3) + 8 * (i >> 2) + 4 * h;
+                const bool ok = (vmask >> ri) & 1ull;
+                P[(mt * 32 + ri) * PSTR + j] = ok ? prelu1(fmaf(acc[i], bs, bt), ba) : 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: 3x3 conv, expansion to 128, pooled residual (+ codes), PReLU --------------------
+    const int nmt_out = (TH * TW) / 32;
+    for (int mt = wave; mt < nmt_out; mt += 4) {
+        float qv[16];
+        conv_tile_q<TW, 3, 3, HW2>(a, P, a.wc, mt, j, h, qv);
+        int ooff[16], xoff[16];
+        unsigned okmask = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ti = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const int rr = ti / TW, cc = ti - rr * TW;
+            const int oy = ty0 + rr, ox = tx0 + cc;
+            const bool ok = (oy < Ho) && (ox < Wo);
+            okmask |= ok ? (1u << i) : 0u;
+            ooff[i] = ok ? oy * Wo + ox : 0;                      // output pixel index
+            xoff[i] = ok ? ((2 * oy) * a.W + 2 * ox) * CDN : 0;  // top-left of the pooling window
+        }
+#pragma unroll 1
+        for (int nt = 0; nt < 4; ++nt) {
+            const int co = nt * 32 + j;
+            float wef[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) wef[k] = a.we[(2 * k + h) * C + co];
+            float rx[16];
+            if (nt < 2) {  // channels < 64 carry the pooled input; wave-uniform branch
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float *w0 = ximg + xoff[i] + co;
+                    const float v00 = w0[0], v01 = w0[CDN];
+                    const float v10 = w0[(long)a.W * CDN], v11 = w0[(long)a.W * CDN + CDN];
+                    float best = v00;  // strict '>' scan in (dy,dx) order: first maximum wins
+                    int cd = 0;
+                    if (v01 > best) { best = v01; cd = 1; }
+                    if (v10 > best) { best = v10; cd = 2; }
+                    if (v11 > best) { best = v11; cd = 3; }
+                    rx[i] = best;
+                    if ((okmask >> i) & 1u) cimg[ooff[i] * CDN + co] = (uint8_t)cd;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) rx[i] = 0.0f;
+            }
+            f32x16 e = {0};
+#pragma unroll
+            for (int s = 0; s < 16; ++s) e = mfma32(qv[ord(s)], wef[s], e);
+            const float s1 = a.es[co], t1 = a.et[co], al = a.ra[co];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float v = prelu1(fmaf(e[i], s1, t1) + rx[i], al);
+                if ((okmask >> i) & 1u) yimg[(long)ooff[i] * C + co] = v;
+            }
+        }
+    }
 }
 
 // =================================================================================================
@@ -679,6 +837,39 @@ __global__ void k_probe_swap(float *out)
 hipError_t launch_probe_swap(float *out, hipStream_t s)
 {
     hipLaunchKernelGGL(k_probe_swap, dim3(1), dim3(64), 0, s, out);
+    return hipGetLastError();
+}
+
+bool downsample_mfma_supported(int Cin, int Cout) { return Cin == CDN && Cout == C; }
+
+hipError_t launch_downsample_mfma(const float *x, float *y, uint8_t *code, int N, int H, int W,
+                                  const float *wp, const float *ps, const float *pt, const float *pa,
+                                  const float *wc, const float *cs, const float *ct, const float *ca,
+                                  const float *we, const float *es, const float *et, const float *ra,
+                                  hipStream_t s)
+{
+    if (H % 2 || W % 2) return hipErrorInvalidValue;
+    DownArgs a;
+    a.x = x; a.y = y; a.code = code;
+    a.wp = wp; a.ps = ps; a.pt = pt; a.pa = pa;
+    a.wc = wc; a.cs = cs; a.ct = ct; a.ca = ca;
+    a.we = we; a.es = es; a.et = et; a.ra = ra;
+    a.N = N; a.H = H; a.W = W;
+    a.TH = 8;
+    const int Ho = H / 2, Wo = W / 2;
+    const bool wide = Wo > 16;
+    const int TW = wide ? 32 : 16;
+    a.tiles_y = (Ho + a.TH - 1) / a.TH;
+    a.tiles_x = (Wo + TW - 1) / TW;
+    const long grid = (long)N * a.tiles_y * a.tiles_x;
+    if (grid <= 0 || grid > 0x7fffffffL) return hipErrorInvalidValue;
+    const double opix = (double)N * Ho * Wo;
+    ProfScope prof("k_downsample_mfma", 2.0 * opix * (4.0 * CDN * F + 9.0 * F * F + F * (double)C),
+                   4.0 * (4.0 * opix * CDN + opix * C) + opix * CDN, s);
+    if (wide)
+        hipLaunchKernelGGL(k_downsample_mfma<32>, dim3((unsigned)grid), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_downsample_mfma<16>, dim3((unsigned)grid), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -277,6 +277,28 @@ def test_upsample_layer_both_unpool_forms_and_families(enet_c3k19, name, n, h, w
             _lib.set_kernel_family(True)
 
 
+@pytest.mark.parametrize("name,n,h,w", [("Bottleneck2_0", 2, 16, 32), ("Bottleneck2_0", 1, 18, 22), ("Bottleneck2_0", 1, 16, 80),
+                                        ("Bottleneck2_0", 1, 2, 2), ("Bottleneck1_0", 2, 16, 32), ("Bottleneck1_0", 1, 6, 10)])
+def test_downsample_layer_both_families(enet_c3k19, name, n, h, w):
+    net, P = enet_c3k19
+    layer = getattr(net, name)
+    cin = layer.proj_kernel.shape[2]
+    rng = np.random.default_rng(20)
+    x = rng.normal(size=(n, h, w, cin)).astype(np.float32)
+    x[0, :2, :2, :] = 0.25  # an all-equal pooling window: the first element must win
+    want, want_arg = orc.bottleneck_down(P, name, x)
+    xd = dev(x)
+    try:
+        for fam in (True, False):
+            _lib.set_kernel_family(fam)
+            got, arg = layer(xd, training=False)
+            tag = "%s family=%s" % (name, "mfma" if fam else "generic")
+            report_diff(tag, got.cpu().numpy(), want)
+            report_diff(tag + " argmax (bit-exact)", arg.cpu().numpy(), want_arg)
+    finally:
+        _lib.set_kernel_family(True)
+
+
 # ---- whole network -------------------------------------------------------------------------------
 def _check_forward(net, P, x, tag):
     ep = {}

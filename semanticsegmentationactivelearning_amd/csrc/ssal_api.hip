@@ -562,7 +562,7 @@ hipError_t run_down(const DevLayer &L, const float *x, int n, int h, int w, floa
 {
     const int C = L.cin, f = L.f;
     if (g_use_mfma && (long)h * w * L.cout < (1L << 31) && downsample_mfma_supported(C, L.cout))
-        return launch_downsample_mfma(x, y, code, n, h, w, L.proj_w, L.proj_scale, L.proj_shift,
+        return launch_downsample_mfma(x, y, code, n, h, w, C, L.proj_w, L.proj_scale, L.proj_shift,
                                       L.proj_alpha, L.conv_w, L.conv_scale, L.conv_shift, L.conv_alpha,
                                       L.exp_w, L.exp_scale, L.exp_shift, L.res_alpha, s);
     ConvArgs p = conv_args(x, n, h, w, C, L.proj_w, 2, 2, f, 2, 1, T.t0);
@@ -584,7 +584,7 @@ hipError_t run_up(const DevLayer &L, const float *x, int n, int h, int w, float 
 {
     const int C = L.cin, pf = L.f, cf = L.cf;
     if (g_use_mfma && code && (long)h * w * 4 * L.cout < (1L << 31) && upsample_mfma_supported(C, L.cout))
-        return launch_upsample_mfma(x, y, code, n, h, w, L.proj_w, L.proj_scale, L.proj_shift,
+        return launch_upsample_mfma(x, y, code, n, h, w, C, L.proj_w, L.proj_scale, L.proj_shift,
                                     L.proj_alpha, L.convT_stacked, L.conv_scale, L.conv_shift,
                                     L.conv_alpha, L.exp_w, L.exp_scale, L.exp_shift, L.res_w,
                                     L.res_alpha, s);

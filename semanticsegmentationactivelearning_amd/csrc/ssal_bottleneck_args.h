@@ -1,0 +1,50 @@
+// ssal_bottleneck_args.h -- kernel argument blocks of the MFMA-fused bottleneck kernels
+// (shared by the 32x32x2 family, ssal_bottleneck_mfma.hip, and the 16x16x4 family,
+// ssal_bottleneck_mfma16.hip).  Channel counts in the comments are those of the 32-wide family;
+// the 16-wide family uses the same fields with its own (smaller) shapes.
+#pragma once
+#include <stdint.h>
+
+namespace ssal {
+
+// regular / dilated / asymmetric bottleneck (enet_modules.py:526-599)
+struct BnkArgs {
+    const float *x;
+    float *y;
+    const float *wp, *ps, *pt, *pa;  // proj kernel [128][32], folded BN, alpha
+    const float *wc, *cs, *ct, *ca;  // conv kernel [3][3][32][32] (HWIO; [5][1][32][32] if asym), folded BN, alpha
+    const float *wc2;                // asymmetric only: second kernel [1][5][32][32]
+    const float *we, *es, *et, *ra;  // exp kernel [32][128], folded BN, residual alpha
+    int N, H, W, dil;
+    int TH;                // tile rows (phase space)
+    int tiles_y, tiles_x;  // tiles per phase sub-image (sized for the largest phase)
+};
+
+// downsample bottleneck (enet_modules.py:868-938)
+struct DownArgs {
+    const float *x;                  // [N,H,W,64]
+    float *y;                        // [N,H/2,W/2,128]
+    uint8_t *code;                   // [N,H/2,W/2,64]
+    const float *wp, *ps, *pt, *pa;  // proj kernel [2][2][64][32], folded BN, alpha
+    const float *wc, *cs, *ct, *ca;  // conv kernel [3][3][32][32]
+    const float *we, *es, *et, *ra;  // exp kernel [32][128]
+    int N, H, W;                     // INPUT dims (even)
+    int TH, tiles_y, tiles_x;
+};
+
+// upsample bottleneck (enet_modules.py:1217-1292)
+struct UpArgs {
+    const float *x;
+    float *y;
+    const uint8_t *code;             // [N,H,W,64] window codes dy*2+dx saved by the matching downsample
+    const float *wp, *ps, *pt, *pa;  // proj kernel [128][32], folded BN, alpha
+    const float *ws;                 // stacked transposed-conv kernel [6][32][32]
+    const float *cs, *ct, *ca;       // [16]
+    const float *we, *es, *et;       // exp kernel [16][64], folded BN [64]
+    const float *wr;                 // residual kernel [128][64]
+    const float *ra;                 // [64]
+    int N, H, W, dil;                // dil == 1
+    int TH, tiles_y, tiles_x;
+};
+
+}  // namespace ssal

@@ -22,48 +22,18 @@
 // An instruction consumes k0 (lanes 0-31) then k1 (lanes 32-63); v_permlane32_swap pairs registers
 // so that consecutive channels sit in the two lane halves (ascending-k accumulation).
 #include "ssal_internal.h"
+#include "ssal_mfma.h"
+#include "ssal_bottleneck_args.h"
 #include "ssal_prof.h"
 
 namespace ssal {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-
-// after the call: a = [a.lo | b.lo], b = [a.hi | b.hi]   (lo = lanes 0-31, hi = lanes 32-63)
-__device__ __forceinline__ void swap32(float &a, float &b)
-{
-    u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    a = __uint_as_float(r[0]);
-    b = __uint_as_float(r[1]);
-}
-
-__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c)
-{
-    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
-
-__device__ __forceinline__ float prelu1(float v, float a) { return v >= 0.0f ? v : a * v; }
 
 constexpr int F = 32;         // bottleneck width
 constexpr int C = 128;        // block channels
 constexpr int PSTR = F + 2;   // LDS pixel stride in dwords: conflict-free ds_read_b64 / ds_write_b32
 constexpr int PMAX = 352;     // >= (TH+2)*(TW+2) rounded up to a multiple of 32
 
-struct BnkArgs {
-    const float *x;
-    float *y;
-    const float *wp, *ps, *pt, *pa;  // proj kernel [128][32], folded BN, alpha
-    const float *wc, *cs, *ct, *ca;  // conv kernel [3][3][32][32] (HWIO; [5][1][32][32] if asym), folded BN, alpha
-    const float *wc2;                // asymmetric only: second kernel [1][5][32][32]
-    const float *we, *es, *et, *ra;  // exp kernel [32][128], folded BN, residual alpha
-    int N, H, W, dil;
-    int TH;                // tile rows (phase space)
-    int tiles_y, tiles_x;  // tiles per phase sub-image (sized for the largest phase)
-};
 
-// register order in which the swapped conv accumulators deliver ascending channel pairs:
-// 0,2,1,3, 4,6,5,7, ...  (swap bits 0 and 1 of the step index)
-__device__ __host__ constexpr int ord(int s) { return (s & ~3) | ((s & 1) << 1) | ((s >> 1) & 1); }
 
 // ---- phase A (shared by the regular and the asymmetric kernel): 1x1 projection + BN + PReLU of the
 // halo'd tile into LDS; pixels outside the image are written as exact zeros (SAME padding of the
@@ -342,16 +312,6 @@ __global__ __launch_bounds__(256, 1) void k_bottleneck_mfma_asym(BnkArgs a)
 // The strided projection is a GEMM with K = (dy,dx,ci) = 4 x 64 over the 2x2 input patch of every
 // (halo'd) output pixel.
 // =================================================================================================
-struct DownArgs {
-    const float *x;                  // [N,H,W,64]
-    float *y;                        // [N,H/2,W/2,128]
-    uint8_t *code;                   // [N,H/2,W/2,64]
-    const float *wp, *ps, *pt, *pa;  // proj kernel [2][2][64][32], folded BN, alpha
-    const float *wc, *cs, *ct, *ca;  // conv kernel [3][3][32][32]
-    const float *we, *es, *et, *ra;  // exp kernel [32][128]
-    int N, H, W;                     // INPUT dims (even)
-    int TH, tiles_y, tiles_x;
-};
 
 constexpr int CDN = 64;  // input channels of the downsample block
 
@@ -495,19 +455,6 @@ __global__ __launch_bounds__(256, 2) void k_downsample_mfma(DownArgs a)
 // [ee | eo], accumulator B carries [oe | oo]; the commit step stacks the kernels accordingly
 // (ws[slot][ci][row], zero rows where a class has no tap: adding an exact zero keeps the chain).
 // =================================================================================================
-struct UpArgs {
-    const float *x;
-    float *y;
-    const uint8_t *code;             // [N,H,W,64] window codes dy*2+dx saved by the matching downsample
-    const float *wp, *ps, *pt, *pa;  // proj kernel [128][32], folded BN, alpha
-    const float *ws;                 // stacked transposed-conv kernel [6][32][32]
-    const float *cs, *ct, *ca;       // [16]
-    const float *we, *es, *et;       // exp kernel [16][64], folded BN [64]
-    const float *wr;                 // residual kernel [128][64]
-    const float *ra;                 // [64]
-    int N, H, W, dil;                // dil == 1
-    int TH, tiles_y, tiles_x;
-};
 
 constexpr int CUP = 64;  // output channels of the upsample block
 
@@ -655,171 +602,6 @@ __global__ __launch_bounds__(256, 2) void k_upsample_mfma(UpArgs a)
     }
 }
 
-// =================================================================================================
-// C = 64 / F = 16 variant (stage 1 and stage 4 bottlenecks) on v_mfma_f32_16x16x4_f32.
-// lane maps (l = lane, i = l & 15, g = l >> 4):  A: A[row i][k = g]   B: B[k = g][col i]
-//   D: reg r holds D[row 4*g + r][col i].  One instruction consumes k = 0,1,2,3 (lane quarters) in
-// order, so quarter g must hold channel 4*s + g at step s: registers that hold 4 consecutive
-// channels per lane are transposed across the four quarters with two permlane swaps per pair.
-// =================================================================================================
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c)
-{
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
-// after the call (q0..q3 = the four 16-lane quarters):
-//   a = [a.q0 b.q0 a.q2 b.q2], b = [a.q1 b.q1 a.q3 b.q3]
-__device__ __forceinline__ void swap16(float &a, float &b)
-{
-    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    a = __uint_as_float(r[0]);
-    b = __uint_as_float(r[1]);
-}
-
-// in: reg r of quarter g holds element 4*g + r;  out: reg r of quarter g holds element 4*r + g
-__device__ __forceinline__ void transpose4(float &r0, float &r1, float &r2, float &r3)
-{
-    swap32(r0, r2);  // r0 = [0 4 2 6], r2 = [8 12 10 14]
-    swap32(r1, r3);  // r1 = [1 5 3 7], r3 = [9 13 11 15]
-    swap16(r0, r1);  // r0 = [0 1 2 3], r1 = [4 5 6 7]
-    swap16(r2, r3);  // r2 = [8 9 10 11], r3 = [12 13 14 15]
-}
-
-constexpr int F16 = 16;
-constexpr int C64 = 64;
-constexpr int PSTR16 = F16 + 2;  // conflict-free ds_read_b32 for 16 consecutive pixels x 2 quarters
-
-template <int TW>
-__global__ __launch_bounds__(256, 4) void k_bottleneck_mfma_f16(BnkArgs a)
-{
-    __shared__ float P[PMAX * PSTR16];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int i16 = lane & 15, g = lane >> 4;
-    const int d = a.dil;
-    constexpr int HW2 = TW + 2;
-
-    int b = blockIdx.x;
-    const int tx = b % a.tiles_x; b /= a.tiles_x;
-    const int ty = b % a.tiles_y; b /= a.tiles_y;
-    const int px = b % d; b /= d;
-    const int py = b % d; b /= d;
-    const int n = b;
-    const int Hp = (a.H - py + d - 1) / d;
-    const int Wp = (a.W - px + d - 1) / d;
-    const int ty0 = ty * a.TH, tx0 = tx * TW;
-    if (ty0 >= Hp || tx0 >= Wp) return;
-    const int TH = a.TH;
-    const int npix_halo = (TH + 2) * HW2;
-    const float *ximg = a.x + (long)n * a.H * a.W * C64;
-
-    // ---- phase A: projection (64 -> 16) on the halo'd tile ---------------------------------------
-    {
-        float wpr[16];
-#pragma unroll
-        for (int s = 0; s < 16; ++s) wpr[s] = a.wp[(4 * s + g) * F16 + i16];
-        const float bs = a.ps[i16], bt = a.pt[i16], ba = a.pa[i16];
-        const int nmt = (npix_halo + 15) / 16;
-        for (int mt = wave; mt < nmt; mt += 4) {
-            const int q = mt * 16 + i16;
-            const int hr = q / HW2, hc = q - hr * HW2;
-            const int pr = ty0 - 1 + hr, pc = tx0 - 1 + hc;
-            const bool valid = (q < npix_halo) && (pr >= 0) && (pr < Hp) && (pc >= 0) && (pc < Wp);
-            const unsigned vmask = (unsigned)(__ballot(valid) & 0xFFFFull);
-            if (vmask == 0u) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) P[(mt * 16 + 4 * g + r) * PSTR16 + i16] = 0.0f;
-                continue;
-            }
-            const float *xp = valid ? ximg + ((long)(py + pr * d) * a.W + (px + pc * d)) * C64 : ximg;
-            float4 v[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m)  // quarter g takes the g-th float4 of every 16 channels
-                v[m] = *reinterpret_cast<const float4 *>(xp + 16 * m + 4 * g);
-            f32x4 acc = {0};
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                float r0 = v[m].x, r1 = v[m].y, r2 = v[m].z, r3 = v[m].w;
-                transpose4(r0, r1, r2, r3);  // reg r of quarter g: channel 16m + 4r + g
-                acc = mfma16(r0, wpr[4 * m + 0], acc);
-                acc = mfma16(r1, wpr[4 * m + 1], acc);
-                acc = mfma16(r2, wpr[4 * m + 2], acc);
-                acc = mfma16(r3, wpr[4 * m + 3], acc);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int pix = 4 * g + r;
-                const bool ok = (vmask >> pix) & 1u;
-                P[(mt * 16 + pix) * PSTR16 + i16] = ok ? prelu1(fmaf(acc[r], bs, bt), ba) : 0.0f;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- phase B: 3x3 conv (16 -> 16) on P, expansion (16 -> 64) + residual ----------------------
-    float cs[4], ct[4], ca[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        cs[r] = a.cs[4 * g + r];
-        ct[r] = a.ct[4 * g + r];
-        ca[r] = a.ca[4 * g + r];
-    }
-    float *yimg = a.y + (long)n * a.H * a.W * C64;
-    const int nmt_out = (TH * TW) / 16;
-    for (int mt = wave; mt < nmt_out; mt += 4) {
-        const int t = mt * 16 + i16;
-        const int r_ = t / TW, c_ = t - r_ * TW;
-        f32x4 acc = {0};
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int kh = tap / 3, kw = tap - 3 * kh;
-            const float *pq = P + ((r_ + kh) * HW2 + (c_ + kw)) * PSTR16 + g;
-            const float *wt = a.wc + (tap * F16 + g) * F16 + i16;
-#pragma unroll
-            for (int s = 0; s < 4; ++s)  // ci = 4s + g: ascending across the lane quarters
-                acc = mfma16(wt[(4 * s) * F16], pq[4 * s], acc);
-        }
-        float q0 = prelu1(fmaf(acc[0], cs[0], ct[0]), ca[0]);
-        float q1 = prelu1(fmaf(acc[1], cs[1], ct[1]), ca[1]);
-        float q2 = prelu1(fmaf(acc[2], cs[2], ct[2]), ca[2]);
-        float q3 = prelu1(fmaf(acc[3], cs[3], ct[3]), ca[3]);
-        transpose4(q0, q1, q2, q3);  // reg s of quarter g: Q[pixel i16][ci = 4s + g]
-
-        int off[4];
-        unsigned okmask = 0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ti = mt * 16 + 4 * g + r;
-            const int rr = ti / TW, cc = ti - rr * TW;
-            const int pr = ty0 + rr, pc = tx0 + cc;
-            const bool ok = (pr < Hp) && (pc < Wp);
-            okmask |= ok ? (1u << r) : 0u;
-            off[r] = ok ? ((py + pr * d) * a.W + (px + pc * d)) * C64 : 0;
-        }
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int co = nt * 16 + i16;
-            float rx[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rx[r] = ximg[off[r] + co];
-            f32x4 e = {0};
-            e = mfma16(q0, a.we[(0 + g) * C64 + co], e);
-            e = mfma16(q1, a.we[(4 + g) * C64 + co], e);
-            e = mfma16(q2, a.we[(8 + g) * C64 + co], e);
-            e = mfma16(q3, a.we[(12 + g) * C64 + co], e);
-            const float s1 = a.es[co], t1 = a.et[co], al = a.ra[co];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = prelu1(fmaf(e[r], s1, t1) + rx[r], al);
-                if ((okmask >> r) & 1u) yimg[off[r] + co] = v;
-            }
-        }
-    }
-}
-
 // one probe for the hardware assumptions this file rests on (tests only): out[0..63] / out[64..127]
 // = the two registers after swap32 of (lane, 100 + lane)
 __global__ void k_probe_swap(float *out)
@@ -840,10 +622,21 @@ hipError_t launch_probe_swap(float *out, hipStream_t s)
     return hipGetLastError();
 }
 
-bool downsample_mfma_supported(int Cin, int Cout) { return Cin == CDN && Cout == C; }
+// 16x16x4 family (ssal_bottleneck_mfma16.hip)
+bool bottleneck_mfma16_supported(int Cin, int f);
+hipError_t launch_bottleneck_mfma16(const BnkArgs &a, int Cin, hipStream_t s);
+bool downsample_mfma16_supported(int Cin, int Cout);
+hipError_t launch_downsample_mfma16(const DownArgs &a, hipStream_t s);
+bool upsample_mfma16_supported(int Cin, int Cout);
+hipError_t launch_upsample_mfma16(const UpArgs &a, hipStream_t s);
+
+bool downsample_mfma_supported(int Cin, int Cout)
+{
+    return (Cin == CDN && Cout == C) || downsample_mfma16_supported(Cin, Cout);
+}
 
 hipError_t launch_downsample_mfma(const float *x, float *y, uint8_t *code, int N, int H, int W,
-                                  const float *wp, const float *ps, const float *pt, const float *pa,
+                                  int Cin, const float *wp, const float *ps, const float *pt, const float *pa,
                                   const float *wc, const float *cs, const float *ct, const float *ca,
                                   const float *we, const float *es, const float *et, const float *ra,
                                   hipStream_t s)
@@ -855,6 +648,7 @@ hipError_t launch_downsample_mfma(const float *x, float *y, uint8_t *code, int N
     a.wc = wc; a.cs = cs; a.ct = ct; a.ca = ca;
     a.we = we; a.es = es; a.et = et; a.ra = ra;
     a.N = N; a.H = H; a.W = W;
+    if (Cin != CDN) return launch_downsample_mfma16(a, s);
     a.TH = 8;
     const int Ho = H / 2, Wo = W / 2;
     const bool wide = Wo > 16;
@@ -873,10 +667,13 @@ hipError_t launch_downsample_mfma(const float *x, float *y, uint8_t *code, int N
     return hipGetLastError();
 }
 
-bool upsample_mfma_supported(int Cin, int Cout) { return Cin == C && Cout == CUP; }
+bool upsample_mfma_supported(int Cin, int Cout)
+{
+    return (Cin == C && Cout == CUP) || upsample_mfma16_supported(Cin, Cout);
+}
 
 hipError_t launch_upsample_mfma(const float *x, float *y, const uint8_t *code, int N, int H, int W,
-                                const float *wp, const float *ps, const float *pt, const float *pa,
+                                int Cin, const float *wp, const float *ps, const float *pt, const float *pa,
                                 const float *ws, const float *cs, const float *ct, const float *ca,
                                 const float *we, const float *es, const float *et, const float *wr,
                                 const float *ra, hipStream_t s)
@@ -887,6 +684,7 @@ hipError_t launch_upsample_mfma(const float *x, float *y, const uint8_t *code, i
     a.ws = ws; a.cs = cs; a.ct = ct; a.ca = ca;
     a.we = we; a.es = es; a.et = et; a.wr = wr; a.ra = ra;
     a.N = N; a.H = H; a.W = W; a.dil = 1;
+    if (Cin != C) return launch_upsample_mfma16(a, s);
     a.TH = 8;
     const bool wide = W > 16;
     const int TW = wide ? 32 : 16;
@@ -907,7 +705,7 @@ hipError_t launch_upsample_mfma(const float *x, float *y, const uint8_t *code, i
 
 bool bottleneck_mfma_supported(int Cin, int f, bool asym)
 {
-    return (Cin == C && f == F) || (!asym && Cin == C64 && f == F16);
+    return (Cin == C && f == F) || (!asym && bottleneck_mfma16_supported(Cin, f));
 }
 
 hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W, int Cin, int dil,
@@ -925,6 +723,7 @@ hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W,
     a.wc = wc; a.wc2 = wc2; a.cs = cs; a.ct = ct; a.ca = ca;
     a.we = we; a.es = es; a.et = et; a.ra = ra;
     a.N = N; a.H = H; a.W = W; a.dil = dil;
+    if (Cin != C) return launch_bottleneck_mfma16(a, Cin, s);
     a.TH = 8;
     const int Hp = (H + dil - 1) / dil, Wp = (W + dil - 1) / dil;  // largest phase sub-image
     const bool wide = Wp > 16;
@@ -936,7 +735,7 @@ hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W,
     const double pix = (double)N * H * W;
     const double f = Cin / 4.0;
     const double taps = asym ? 10.0 : 9.0;
-    ProfScope prof(asym ? "k_bottleneck_mfma_asym" : (Cin == C ? "k_bottleneck_mfma" : "k_bottleneck_mfma_f16"),
+    ProfScope prof(asym ? "k_bottleneck_mfma_asym" : "k_bottleneck_mfma",
                    2.0 * pix * (Cin * f + taps * f * f + f * Cin),
                    4.0 * (2.0 * pix * Cin + Cin * f * 2.0 + taps * f * f), s);
     if (asym) {
@@ -944,18 +743,11 @@ hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W,
             hipLaunchKernelGGL(k_bottleneck_mfma_asym<32>, dim3((unsigned)grid), dim3(256), 0, s, a);
         else
             hipLaunchKernelGGL(k_bottleneck_mfma_asym<16>, dim3((unsigned)grid), dim3(256), 0, s, a);
-    } else if (Cin == C) {
+    } else {
         if (wide)
             hipLaunchKernelGGL(k_bottleneck_mfma<32>, dim3((unsigned)grid), dim3(256), 0, s, a);
         else
             hipLaunchKernelGGL(k_bottleneck_mfma<16>, dim3((unsigned)grid), dim3(256), 0, s, a);
-    } else if (Cin == C64) {
-        if (wide)
-            hipLaunchKernelGGL(k_bottleneck_mfma_f16<32>, dim3((unsigned)grid), dim3(256), 0, s, a);
-        else
-            hipLaunchKernelGGL(k_bottleneck_mfma_f16<16>, dim3((unsigned)grid), dim3(256), 0, s, a);
-    } else {
-        return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }

@@ -1,0 +1,492 @@
+// ssal_bottleneck_mfma16.hip -- the narrow ENet blocks (bottleneck width <= 16) fused on
+// v_mfma_f32_16x16x4_f32:  regular bottlenecks of stage 1/4 (C=64, F=16) and stage 5 (C=16, F=4),
+// the 64 -> 16 upsample block (Bottleneck5_0) and the 16 -> 64 downsample block (Bottleneck1_0).
+// Same structure, same accumulation order (bit-identical results) as the 32-wide family in
+// ssal_bottleneck_mfma.hip; these blocks sit at 1/2 and 1/4 resolution with 16-64 channels and are
+// HBM-bound, so the point of the fusion is one read of the input and one write of the output.
+//
+// lane maps (l = lane, i = l & 15, g = l >> 4):  A[row i][k = g],  B[k = g][col i],
+// D reg r = D[row 4g + r][col i].  An instruction consumes k = 0..3 in lane-quarter order, so quarter
+// g feeds channel 4s + g at step s; transpose4() produces that from per-lane consecutive channels.
+// Bottleneck widths below 16 use zero-padded weight columns (exact: adds +0 to unused rows).
+#include "ssal_internal.h"
+#include "ssal_mfma.h"
+#include "ssal_bottleneck_args.h"
+#include "ssal_prof.h"
+
+namespace ssal {
+
+constexpr int PMAX16 = 352;  // >= (8+2)*(32+2), multiple of 16
+
+// ---- phase A: 1x1 projection CC -> FF (+BN +PReLU) of the halo'd tile into LDS P[pixel][FF (+2)] ----
+template <int TW, int CC, int FF, typename Args>
+__device__ __forceinline__ void proj16_to_lds(const Args &a, const float *ximg, float *P, int TH,
+                                              int ty0, int tx0, int py, int px, int Hp, int Wp,
+                                              int wave, int i16, int g)
+{
+    constexpr int PS = FF + 2, HW2 = TW + 2, KP = CC / 4;
+    const int d = a.dil;
+    const int npix_halo = (TH + 2) * HW2;
+    const bool cval = i16 < FF;
+    const int ic = cval ? i16 : 0;
+    float wpr[KP];
+#pragma unroll
+    for (int s = 0; s < KP; ++s) {
+        const float w = a.wp[(4 * s + g) * FF + ic];
+        wpr[s] = cval ? w : 0.0f;
+    }
+    const float bs = a.ps[ic], bt = a.pt[ic], ba = a.pa[ic];
+    const int nmt = (npix_halo + 15) / 16;
+    for (int mt = wave; mt < nmt; mt += 4) {
+        const int q = mt * 16 + i16;
+        const int hr = q / HW2, hc = q - hr * HW2;
+        const int pr = ty0 - 1 + hr, pc = tx0 - 1 + hc;
+        const bool valid = (q < npix_halo) && (pr >= 0) && (pr < Hp) && (pc >= 0) && (pc < Wp);
+        const unsigned vmask = (unsigned)(__ballot(valid) & 0xFFFFull);
+        if (vmask == 0u) {
+            if (cval) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) P[(mt * 16 + 4 * g + r) * PS + i16] = 0.0f;
+            }
+            continue;
+        }
+        const float *xp = valid ? ximg + ((long)(py + pr * d) * a.W + (px + pc * d)) * CC : ximg;
+        float4 v[CC / 16];
+#pragma unroll
+        for (int m = 0; m < CC / 16; ++m)  // quarter g takes the g-th float4 of every 16 channels
+            v[m] = *reinterpret_cast<const float4 *>(xp + 16 * m + 4 * g);
+        f32x4 acc = {0};
+#pragma unroll
+        for (int m = 0; m < CC / 16; ++m) {
+            float r0 = v[m].x, r1 = v[m].y, r2 = v[m].z, r3 = v[m].w;
+            transpose4(r0, r1, r2, r3);  // reg r of quarter g: channel 16m + 4r + g
+            acc = mfma16(r0, wpr[4 * m + 0], acc);
+            acc = mfma16(r1, wpr[4 * m + 1], acc);
+            acc = mfma16(r2, wpr[4 * m + 2], acc);
+            acc = mfma16(r3, wpr[4 * m + 3], acc);
+        }
+        if (cval) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pix = 4 * g + r;
+                const bool ok = (vmask >> pix) & 1u;
+                P[(mt * 16 + pix) * PS + i16] = ok ? prelu1(fmaf(acc[r], bs, bt), ba) : 0.0f;
+            }
+        }
+    }
+}
+
+// ---- 3x3 conv FF -> FF over the LDS tile for one 16-pixel M-tile, + BN + PReLU; returns the result
+// as expansion A operand: q[s] of lane (pixel i16, quarter g) = Q[pixel][ci = 4s + g] ---------------
+template <int TW, int FF, typename Args>
+__device__ __forceinline__ void conv16_tile_q(const Args &a, const float *P, int mt, int i16, int g,
+                                              float (&q)[4])
+{
+    constexpr int PS = FF + 2, HW2 = TW + 2, KF = FF / 4;
+    const int t = mt * 16 + i16;
+    const int r_ = t / TW, c_ = t - r_ * TW;
+    const bool cval = i16 < FF;
+    const int ic = cval ? i16 : 0;
+    f32x4 acc = {0};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        const float *pq = P + ((r_ + kh) * HW2 + (c_ + kw)) * PS + g;
+        const float *wt = a.wc + (tap * FF + g) * FF + ic;
+#pragma unroll
+        for (int s = 0; s < KF; ++s) {  // ci = 4s + g: ascending across the lane quarters
+            const float w = wt[(4 * s) * FF];
+            acc = mfma16(cval ? w : 0.0f, pq[4 * s], acc);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = 4 * g + r;
+        const bool ok = co < FF;
+        const int cc = ok ? co : 0;
+        const float v = prelu1(fmaf(acc[r], a.cs[cc], a.ct[cc]), a.ca[cc]);
+        q[r] = ok ? v : 0.0f;
+    }
+    transpose4(q[0], q[1], q[2], q[3]);
+}
+
+// =================================================================================================
+// regular / dilated bottleneck, CC channels, width FF = CC/4   (Bottleneck.call, enet_modules.py:526-599)
+// =================================================================================================
+template <int TW, int CC, int FF>
+__global__ __launch_bounds__(256, 4) void k_bottleneck16(BnkArgs a)
+{
+    constexpr int PS = FF + 2, KF = FF / 4, NT = CC / 16;
+    __shared__ float P[PMAX16 * PS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int d = a.dil;
+    int b = blockIdx.x;
+    const int tx = b % a.tiles_x; b /= a.tiles_x;
+    const int ty = b % a.tiles_y; b /= a.tiles_y;
+    const int px = b % d; b /= d;
+    const int py = b % d; b /= d;
+    const int n = b;
+    const int Hp = (a.H - py + d - 1) / d;
+    const int Wp = (a.W - px + d - 1) / d;
+    const int TH = a.TH;
+    const int ty0 = ty * TH, tx0 = tx * TW;
+    if (ty0 >= Hp || tx0 >= Wp) return;
+    const float *ximg = a.x + (long)n * a.H * a.W * CC;
+    float *yimg = a.y + (long)n * a.H * a.W * CC;
+
+    proj16_to_lds<TW, CC, FF>(a, ximg, P, TH, ty0, tx0, py, px, Hp, Wp, wave, i16, g);
+    __syncthreads();
+
+    const int nmt_out = (TH * TW) / 16;
+    for (int mt = wave; mt < nmt_out; mt += 4) {
+        float q[4];
+        conv16_tile_q<TW, FF>(a, P, mt, i16, g, q);
+        int off[4];
+        unsigned okmask = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ti = mt * 16 + 4 * g + r;
+            const int rr = ti / TW, cc = ti - rr * TW;
+            const int pr = ty0 + rr, pc = tx0 + cc;
+            const bool ok = (pr < Hp) && (pc < Wp);
+            okmask |= ok ? (1u << r) : 0u;
+            off[r] = ok ? ((py + pr * d) * a.W + (px + pc * d)) * CC : 0;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int co = nt * 16 + i16;
+            float rx[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rx[r] = ximg[off[r] + co];
+            f32x4 e = {0};
+#pragma unroll
+            for (int s = 0; s < KF; ++s) e = mfma16(q[s], a.we[(4 * s + g) * CC + co], e);
+            const float s1 = a.es[co], t1 = a.et[co], al = a.ra[co];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = prelu1(fmaf(e[r], s1, t1) + rx[r], al);
+                if ((okmask >> r) & 1u) yimg[off[r] + co] = v;
+            }
+        }
+    }
+}
+
+// =================================================================================================
+// downsample bottleneck 16 -> 64, width 8 (Bottleneck1_0; enet_modules.py:868-938)
+// =================================================================================================
+template <int TW>
+__global__ __launch_bounds__(256, 4) void k_downsample16(DownArgs a)
+{
+    constexpr int CI = 16, FF = 8, CO = 64, PS = FF + 2, HW2 = TW + 2;
+    __shared__ float P[PMAX16 * PS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int Ho = a.H / 2, Wo = a.W / 2;
+    int b = blockIdx.x;
+    const int tx = b % a.tiles_x; b /= a.tiles_x;
+    const int ty = b % a.tiles_y; b /= a.tiles_y;
+    const int n = b;
+    const int TH = a.TH;
+    const int ty0 = ty * TH, tx0 = tx * TW;
+    const float *ximg = a.x + (long)n * a.H * a.W * CI;
+    float *yimg = a.y + (long)n * Ho * Wo * CO;
+    uint8_t *cimg = a.code + (long)n * Ho * Wo * CI;
+    const bool cval = i16 < FF;
+    const int ic = cval ? i16 : 0;
+
+    // ---- phase A: 2x2/s2 projection (K = 4 taps x 16 ci) of the halo'd output tile -> LDS ----------
+    {
+        float wpr[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {  // step s = 4*tap + s': ci = 4s' + g of tap (dy,dx)
+            const float w = a.wp[((s >> 2) * CI + 4 * (s & 3) + g) * FF + ic];
+            wpr[s] = cval ? w : 0.0f;
+        }
+        const float bs = a.ps[ic], bt = a.pt[ic], ba = a.pa[ic];
+        const int npix_halo = (TH + 2) * HW2;
+        const int nmt = (npix_halo + 15) / 16;
+        for (int mt = wave; mt < nmt; mt += 4) {
+            const int q = mt * 16 + i16;
+            const int hr = q / HW2, hc = q - hr * HW2;
+            const int pr = ty0 - 1 + hr, pc = tx0 - 1 + hc;
+            const bool valid = (q < npix_halo) && (pr >= 0) && (pr < Ho) && (pc >= 0) && (pc < Wo);
+            const unsigned vmask = (unsigned)(__ballot(valid) & 0xFFFFull);
+            if (vmask == 0u) {
+                if (cval) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) P[(mt * 16 + 4 * g + r) * PS + i16] = 0.0f;
+                }
+                continue;
+            }
+            const float *xp = valid ? ximg + ((long)(2 * pr) * a.W + 2 * pc) * CI : ximg;
+            float4 v[4];
+#pragma unroll
+            for (int tap = 0; tap < 4; ++tap)
+                v[tap] = *reinterpret_cast<const float4 *>(xp + ((tap >> 1) * a.W + (tap & 1)) * CI + 4 * g);
+            f32x4 acc = {0};
+#pragma unroll
+            for (int tap = 0; tap < 4; ++tap) {
+                float r0 = v[tap].x, r1 = v[tap].y, r2 = v[tap].z, r3 = v[tap].w;
+                transpose4(r0, r1, r2, r3);
+                acc = mfma16(r0, wpr[4 * tap + 0], acc);
+                acc = mfma16(r1, wpr[4 * tap + 1], acc);
+                acc = mfma16(r2, wpr[4 * tap + 2], acc);
+                acc = mfma16(r3, wpr[4 * tap + 3], acc);
+            }
+            if (cval) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int pix = 4 * g + r;
+                    const bool ok = (vmask >> pix) & 1u;
+                    P[(mt * 16 + pix) * PS + i16] = ok ? prelu1(fmaf(acc[r], bs, bt), ba) : 0.0f;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: 3x3 conv (8 -> 8), expansion (8 -> 64), pooled residual + codes -------------------
+    const int nmt_out = (TH * TW) / 16;
+    for (int mt = wave; mt < nmt_out; mt += 4) {
+        float q[4];
+        conv16_tile_q<TW, FF>(a, P, mt, i16, g, q);
+        int ooff[4], xoff[4];
+        unsigned okmask = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ti = mt * 16 + 4 * g + r;
+            const int rr = ti / TW, cc = ti - rr * TW;
+            const int oy = ty0 + rr, ox = tx0 + cc;
+            const bool ok = (oy < Ho) && (ox < Wo);
+            okmask |= ok ? (1u << r) : 0u;
+            ooff[r] = ok ? oy * Wo + ox : 0;
+            xoff[r] = ok ? ((2 * oy) * a.W + 2 * ox) * CI : 0;
+        }
+#pragma unroll
+        for (int nt = 0; nt < CO / 16; ++nt) {
+            const int co = nt * 16 + i16;
+            float rx[4];
+            if (nt == 0) {  // channels < 16 carry the pooled block input (first maximum wins)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float *w0 = ximg + xoff[r] + co;
+                    const float v00 = w0[0], v01 = w0[CI];
+                    const float v10 = w0[(long)a.W * CI], v11 = w0[(long)a.W * CI + CI];
+                    float best = v00;
+                    int cd = 0;
+                    if (v01 > best) { best = v01; cd = 1; }
+                    if (v10 > best) { best = v10; cd = 2; }
+                    if (v11 > best) { best = v11; cd = 3; }
+                    rx[r] = best;
+                    if ((okmask >> r) & 1u) cimg[ooff[r] * CI + co] = (uint8_t)cd;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rx[r] = 0.0f;
+            }
+            f32x4 e = {0};
+            e = mfma16(q[0], a.we[(0 + g) * CO + co], e);
+            e = mfma16(q[1], a.we[(4 + g) * CO + co], e);
+            const float s1 = a.es[co], t1 = a.et[co], al = a.ra[co];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = prelu1(fmaf(e[r], s1, t1) + rx[r], al);
+                if ((okmask >> r) & 1u) yimg[(long)ooff[r] * CO + co] = v;
+            }
+        }
+    }
+}
+
+// =================================================================================================
+// upsample bottleneck 64 -> 16 (Bottleneck5_0; enet_modules.py:1217-1292): proj 64 -> 16, transposed
+// conv 16 -> 8 with two output-parity classes stacked in the 16 MFMA rows ([ee|eo] and [oe|oo], see
+// ssal_bottleneck_mfma.hip), exp 8 -> 16, residual 1x1 conv 64 -> 16 + gather-unpool.
+// =================================================================================================
+template <int TW>
+__global__ __launch_bounds__(256, 4) void k_upsample16(UpArgs a)
+{
+    constexpr int CI = 64, PF = 16, CF = 8, CO = 16, PS = PF + 2, HW2 = TW + 2;
+    __shared__ float P[PMAX16 * PS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    int b = blockIdx.x;
+    const int tx = b % a.tiles_x; b /= a.tiles_x;
+    const int ty = b % a.tiles_y; b /= a.tiles_y;
+    const int n = b;
+    const int TH = a.TH;
+    const int ty0 = ty * TH, tx0 = tx * TW;
+    const float *ximg = a.x + (long)n * a.H * a.W * CI;
+    const uint8_t *cimg = a.code + (long)n * a.H * a.W * CO;
+    float *yimg = a.y + (long)n * 4 * a.H * a.W * CO;
+
+    proj16_to_lds<TW, CI, PF>(a, ximg, P, TH, ty0, tx0, 0, 0, a.H, a.W, wave, i16, g);
+    __syncthreads();
+
+    // BN + PReLU constants of the transposed conv: reg r of quarter g holds channel 4*(g&1) + r
+    float cs[4], ct[4], ca[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = 4 * (g & 1) + r;
+        cs[r] = a.cs[co]; ct[r] = a.ct[co]; ca[r] = a.ca[co];
+    }
+    const float s1 = a.es[i16], t1 = a.et[i16], al = a.ra[i16];
+    const float we0 = a.we[(0 + g) * CO + i16], we1 = a.we[(4 + g) * CO + i16];
+
+    const int nmt = (TH * TW) / 16;
+    for (int mt = wave; mt < nmt; mt += 4) {
+        const int t = mt * 16 + i16;
+        const int r_ = t / TW, c_ = t - r_ * TW;
+        const bool lane_ok = (ty0 + r_ < a.H) && (tx0 + c_ < a.W);
+
+        // ---- residual branch: D[pixel][co] = X[pixel][ci] * Wr[ci][co]  (64 -> 16) ------------------
+        f32x4 res = {0};
+        {
+            const float *xp = lane_ok ? ximg + ((long)(ty0 + r_) * a.W + (tx0 + c_)) * CI : ximg;
+            float4 v[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) v[m] = *reinterpret_cast<const float4 *>(xp + 16 * m + 4 * g);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                float r0 = v[m].x, r1 = v[m].y, r2 = v[m].z, r3 = v[m].w;
+                transpose4(r0, r1, r2, r3);
+                res = mfma16(r0, a.wr[(16 * m + 0 + g) * CO + i16], res);
+                res = mfma16(r1, a.wr[(16 * m + 4 + g) * CO + i16], res);
+                res = mfma16(r2, a.wr[(16 * m + 8 + g) * CO + i16], res);
+                res = mfma16(r3, a.wr[(16 * m + 12 + g) * CO + i16], res);
+            }
+        }
+
+        // ---- transposed conv 16 -> 8: accA rows [ee|eo], accB rows [oe|oo] ---------------------------
+        f32x4 accA = {0}, accB = {0};
+#pragma unroll
+        for (int slot = 0; slot < 6; ++slot) {
+            const int dr = slot < 4 ? 1 - (slot >> 1) : 1, dc = 1 - (slot & 1);
+            const float *pq = P + ((r_ + dr) * HW2 + (c_ + dc)) * PS + g;
+            const float *wt = a.ws + (slot * PF + g) * 16 + i16;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (slot < 4) accA = mfma16(wt[(4 * s) * 16], pq[4 * s], accA);
+                else          accB = mfma16(wt[(4 * s) * 16], pq[4 * s], accB);
+            }
+        }
+        float qa[4], qb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            qa[r] = prelu1(fmaf(accA[r], cs[r], ct[r]), ca[r]);
+            qb[r] = prelu1(fmaf(accB[r], cs[r], ct[r]), ca[r]);
+        }
+        // after the transpose: regs 0,1 = first class (ci = g, 4+g), regs 2,3 = second class
+        transpose4(qa[0], qa[1], qa[2], qa[3]);
+        transpose4(qb[0], qb[1], qb[2], qb[3]);
+
+        int ooff[4], coff[4];
+        unsigned okmask = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ti = mt * 16 + 4 * g + r;
+            const int rr = ti / TW, cc = ti - rr * TW;
+            const int iy = ty0 + rr, ix = tx0 + cc;
+            const bool ok = (iy < a.H) && (ix < a.W);
+            okmask |= ok ? (1u << r) : 0u;
+            coff[r] = ok ? (iy * a.W + ix) * CO : 0;
+            ooff[r] = ok ? ((2 * iy) * (2 * a.W) + 2 * ix) * CO : 0;
+        }
+        int cd[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cd[r] = cimg[coff[r] + i16];
+#pragma unroll
+        for (int cls = 0; cls < 4; ++cls) {  // ee, eo, oe, oo == window code dy*2+dx
+            const float a0 = cls < 2 ? qa[(cls & 1) * 2] : qb[(cls & 1) * 2];
+            const float a1 = cls < 2 ? qa[(cls & 1) * 2 + 1] : qb[(cls & 1) * 2 + 1];
+            f32x4 e = {0};
+            e = mfma16(a0, we0, e);
+            e = mfma16(a1, we1, e);
+            const int shift = ((cls >> 1) * (2 * a.W) + (cls & 1)) * CO;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float rsd = (cd[r] == cls) ? res[r] : 0.0f;
+                const float v = prelu1(fmaf(e[r], s1, t1) + rsd, al);
+                if ((okmask >> r) & 1u) yimg[ooff[r] + shift + i16] = v;
+            }
+        }
+    }
+    (void)CF;
+}
+
+// =================================================================================================
+// launchers
+// =================================================================================================
+bool bottleneck_mfma16_supported(int Cin, int f) { return (Cin == 64 && f == 16) || (Cin == 16 && f == 4); }
+
+hipError_t launch_bottleneck_mfma16(const BnkArgs &a0, int Cin, hipStream_t s)
+{
+    BnkArgs a = a0;
+    a.TH = 8;
+    const int Hp = (a.H + a.dil - 1) / a.dil, Wp = (a.W + a.dil - 1) / a.dil;
+    const bool wide = Wp > 16;
+    const int TW = wide ? 32 : 16;
+    a.tiles_y = (Hp + a.TH - 1) / a.TH;
+    a.tiles_x = (Wp + TW - 1) / TW;
+    const long grid = (long)a.N * a.dil * a.dil * a.tiles_y * a.tiles_x;
+    if (grid <= 0 || grid > 0x7fffffffL) return hipErrorInvalidValue;
+    const double pix = (double)a.N * a.H * a.W, f = Cin / 4.0;
+    ProfScope prof(Cin == 64 ? "k_bottleneck16<64,16>" : "k_bottleneck16<16,4>",
+                   2.0 * pix * (Cin * f + 9.0 * f * f + f * Cin), 4.0 * 2.0 * pix * Cin, s);
+    dim3 G((unsigned)grid), B(256);
+    if (Cin == 64) {
+        if (wide) hipLaunchKernelGGL((k_bottleneck16<32, 64, 16>), G, B, 0, s, a);
+        else      hipLaunchKernelGGL((k_bottleneck16<16, 64, 16>), G, B, 0, s, a);
+    } else if (Cin == 16) {
+        if (wide) hipLaunchKernelGGL((k_bottleneck16<32, 16, 4>), G, B, 0, s, a);
+        else      hipLaunchKernelGGL((k_bottleneck16<16, 16, 4>), G, B, 0, s, a);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+bool downsample_mfma16_supported(int Cin, int Cout) { return Cin == 16 && Cout == 64; }
+
+hipError_t launch_downsample_mfma16(const DownArgs &a0, hipStream_t s)
+{
+    DownArgs a = a0;
+    if (a.H % 2 || a.W % 2) return hipErrorInvalidValue;
+    a.TH = 8;
+    const int Ho = a.H / 2, Wo = a.W / 2;
+    const bool wide = Wo > 16;
+    const int TW = wide ? 32 : 16;
+    a.tiles_y = (Ho + a.TH - 1) / a.TH;
+    a.tiles_x = (Wo + TW - 1) / TW;
+    const long grid = (long)a.N * a.tiles_y * a.tiles_x;
+    if (grid <= 0 || grid > 0x7fffffffL) return hipErrorInvalidValue;
+    const double opix = (double)a.N * Ho * Wo;
+    ProfScope prof("k_downsample16", 2.0 * opix * (4.0 * 16 * 8 + 9.0 * 8 * 8 + 8.0 * 64),
+                   4.0 * (4.0 * opix * 16 + opix * 64) + opix * 16, s);
+    if (wide) hipLaunchKernelGGL(k_downsample16<32>, dim3((unsigned)grid), dim3(256), 0, s, a);
+    else      hipLaunchKernelGGL(k_downsample16<16>, dim3((unsigned)grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+bool upsample_mfma16_supported(int Cin, int Cout) { return Cin == 64 && Cout == 16; }
+
+hipError_t launch_upsample_mfma16(const UpArgs &a0, hipStream_t s)
+{
+    UpArgs a = a0;
+    a.dil = 1;
+    a.TH = 8;
+    const bool wide = a.W > 16;
+    const int TW = wide ? 32 : 16;
+    a.tiles_y = (a.H + a.TH - 1) / a.TH;
+    a.tiles_x = (a.W + TW - 1) / TW;
+    const long grid = (long)a.N * a.tiles_y * a.tiles_x;
+    if (grid <= 0 || grid > 0x7fffffffL) return hipErrorInvalidValue;
+    const double pix = (double)a.N * a.H * a.W;
+    ProfScope prof("k_upsample16", 2.0 * pix * (64.0 * 16 + 9.0 * 16 * 8 + 4.0 * 8 * 16 + 64.0 * 16),
+                   4.0 * (pix * 64 + 4.0 * pix * 16) + pix * 16, s);
+    if (wide) hipLaunchKernelGGL(k_upsample16<32>, dim3((unsigned)grid), dim3(256), 0, s, a);
+    else      hipLaunchKernelGGL(k_upsample16<16>, dim3((unsigned)grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace ssal

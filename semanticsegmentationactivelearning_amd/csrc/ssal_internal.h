@@ -77,17 +77,17 @@ hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W,
                                   const float *wc, const float *wc2 /* asym: (1,5) kernel, else NULL */,
                                   const float *cs, const float *ct, const float *ca, const float *we,
                                   const float *es, const float *et, const float *ra, hipStream_t s);
-// MFMA-fused downsample bottleneck 64 -> 128 (writes the 2x2 window codes)
+// MFMA-fused downsample bottleneck 64 -> 128 / 16 -> 64 (writes the 2x2 window codes)
 bool downsample_mfma_supported(int Cin, int Cout);
 hipError_t launch_downsample_mfma(const float *x, float *y, uint8_t *code, int N, int H, int W,
-                                  const float *wp, const float *ps, const float *pt, const float *pa,
+                                  int Cin, const float *wp, const float *ps, const float *pt, const float *pa,
                                   const float *wc, const float *cs, const float *ct, const float *ca,
                                   const float *we, const float *es, const float *et, const float *ra,
                                   hipStream_t s);
-// MFMA-fused upsample bottleneck 128 -> 64 (window-code unpooling); ws = stacked transposed-conv kernel
+// MFMA-fused upsample bottleneck 128 -> 64 / 64 -> 16 (window-code unpooling); ws = stacked transposed-conv kernel
 bool upsample_mfma_supported(int Cin, int Cout);
 hipError_t launch_upsample_mfma(const float *x, float *y, const uint8_t *code, int N, int H, int W,
-                                const float *wp, const float *ps, const float *pt, const float *pa,
+                                int Cin, const float *wp, const float *ps, const float *pt, const float *pa,
                                 const float *ws, const float *cs, const float *ct, const float *ca,
                                 const float *we, const float *es, const float *et, const float *wr,
                                 const float *ra, hipStream_t s);

@@ -1,0 +1,64 @@
+// ssal_mfma.h -- gfx950 fp32-input MFMA helpers shared by the fused bottleneck kernels.
+//
+// v_mfma_f32_32x32x2_f32  (l = lane, r = l & 31, h = l >> 5):
+//   A: lane holds A[row r][k = h]    B: lane holds B[k = h][col r]
+//   D: reg i of lane holds D[row (i&3) + 8*(i>>2) + 4*h][col r]          (16 registers)
+// v_mfma_f32_16x16x4_f32  (i = l & 15, g = l >> 4):
+//   A: A[row i][k = g]               B: B[k = g][col i]
+//   D: reg r holds D[row 4*g + r][col i]                                  (4 registers)
+// Both are exact fp32: the result is a k-ordered fmaf chain (k = 0.. within an instruction, then
+// instruction order), which is what lets the kernels be bit-identical to the parity oracle as long
+// as every operand is fed in ascending (kh, kw, ci) order.  The permlane helpers below re-arrange
+// registers that hold consecutive channels per lane into that order without touching LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ssal {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// after the call: a = [a.lo | b.lo], b = [a.hi | b.hi]   (lo = lanes 0-31, hi = lanes 32-63)
+__device__ __forceinline__ void swap32(float &a, float &b)
+{
+    u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+
+// after the call (q0..q3 = the four 16-lane quarters):
+//   a = [a.q0 b.q0 a.q2 b.q2], b = [a.q1 b.q1 a.q3 b.q3]
+__device__ __forceinline__ void swap16(float &a, float &b)
+{
+    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+
+// in: reg r of quarter g holds element 4*g + r;  out: reg r of quarter g holds element 4*r + g
+__device__ __forceinline__ void transpose4(float &r0, float &r1, float &r2, float &r3)
+{
+    swap32(r0, r2);  // r0 = [0 4 2 6], r2 = [8 12 10 14]
+    swap32(r1, r3);  // r1 = [1 5 3 7], r3 = [9 13 11 15]
+    swap16(r0, r1);  // r0 = [0 1 2 3], r1 = [4 5 6 7]
+    swap16(r2, r3);  // r2 = [8 9 10 11], r3 = [12 13 14 15]
+}
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float prelu1(float v, float a) { return v >= 0.0f ? v : a * v; }
+
+// 32x32x2 family: register order in which pair-swapped accumulator registers deliver ascending
+// channel pairs: 0,2,1,3, 4,6,5,7, ...  (swap bits 0 and 1 of the step index)
+__device__ __host__ constexpr int ord(int s) { return (s & ~3) | ((s & 1) << 1) | ((s >> 1) & 1); }
+
+}  // namespace ssal

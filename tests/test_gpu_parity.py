@@ -235,6 +235,7 @@ def test_permlane32_swap_lane_semantics():
     ("Bottleneck4_2", 1, 1, 1), ("Bottleneck1_2", 1, 8, 40),
     ("Bottleneck2_3", 2, 16, 32), ("Bottleneck2_7", 1, 9, 11), ("Bottleneck3_3", 1, 24, 72), ("Bottleneck3_7", 2, 32, 64),
     ("Bottleneck2_3", 1, 1, 1), ("Bottleneck3_7", 1, 8, 40), ("Bottleneck2_7", 1, 5, 3),
+    ("Bottleneck5_1", 2, 16, 32), ("Bottleneck5_1", 1, 9, 11), ("Bottleneck5_1", 1, 24, 72), ("Bottleneck5_1", 1, 1, 1),
 ])
 def test_mfma_bottleneck_equals_generic_and_oracle(enet_c3k19, name, n, h, w):
     net, P = enet_c3k19

@@ -18,6 +18,8 @@ struct BnkArgs {
     int N, H, W, dil;
     int TH;                // tile rows (phase space)
     int tiles_y, tiles_x;  // tiles per phase sub-image (sized for the largest phase)
+    int ablate;            // measurement aid (SSAL_ABLATE env): 1 = stop after the projection phase,
+                           // 2 = skip the projection phase (results invalid; timing only)
 };
 
 // downsample bottleneck (enet_modules.py:868-938)

@@ -25,6 +25,7 @@
 #include "ssal_mfma.h"
 #include "ssal_bottleneck_args.h"
 #include "ssal_prof.h"
+#include <stdlib.h>
 
 namespace ssal {
 
@@ -275,8 +276,10 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck_mfma(BnkArgs a)
     if (t.empty) return;  // whole workgroup: no barrier has been reached yet
     const float *ximg = a.x + (long)t.n * a.H * a.W * C;
     float *yimg = a.y + (long)t.n * a.H * a.W * C;
-    proj_to_lds<TW, 1>(a, ximg, P, a.TH, t.ty0, t.tx0, t.py, t.px, t.Hp, t.Wp, wave, j, h);
+    if (a.ablate != 2)
+        proj_to_lds<TW, 1>(a, ximg, P, a.TH, t.ty0, t.tx0, t.py, t.px, t.Hp, t.Wp, wave, j, h);
     __syncthreads();
+    if (a.ablate == 1) return;
     conv_exp_store<TW, 3, 3, TW + 2>(a, ximg, yimg, P, a.wc, a.TH, t.ty0, t.tx0, t.py, t.px, t.Hp,
                                      t.Wp, wave, j, h);
 }
@@ -723,6 +726,10 @@ hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W,
     a.wc = wc; a.wc2 = wc2; a.cs = cs; a.ct = ct; a.ca = ca;
     a.we = we; a.es = es; a.et = et; a.ra = ra;
     a.N = N; a.H = H; a.W = W; a.dil = dil;
+    {
+        static const int ablate = getenv("SSAL_ABLATE") ? atoi(getenv("SSAL_ABLATE")) : 0;
+        a.ablate = ablate;
+    }
     if (Cin != C) return launch_bottleneck_mfma16(a, Cin, s);
     a.TH = 8;
     const int Hp = (H + dil - 1) / dil, Wp = (W + dil - 1) / dil;  // largest phase sub-image

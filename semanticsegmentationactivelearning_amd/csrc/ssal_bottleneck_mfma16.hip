@@ -76,42 +76,71 @@ __device__ __forceinline__ void proj16_to_lds(const Args &a, const float *ximg, 
     }
 }
 
+// ---- weights of the 3x3 conv FF -> FF as A-operand fragments, loaded ONCE per wave (they are
+// identical for every M-tile): wcr[tap*KF + s] = Wc[tap][ci = 4s + g][co = i16] (0 beyond FF) ------
+template <int FF, typename Args>
+__device__ __forceinline__ void load_conv16_weights(const Args &a, int i16, int g, float (&wcr)[9 * (FF / 4)])
+{
+    constexpr int KF = FF / 4;
+    const bool cval = i16 < FF;
+    const int ic = cval ? i16 : 0;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int s = 0; s < KF; ++s) {
+            const float w = a.wc[((tap * FF) + 4 * s + g) * FF + ic];
+            wcr[tap * KF + s] = cval ? w : 0.0f;
+        }
+}
+
 // ---- 3x3 conv FF -> FF over the LDS tile for one 16-pixel M-tile, + BN + PReLU; returns the result
-// as expansion A operand: q[s] of lane (pixel i16, quarter g) = Q[pixel][ci = 4s + g] ---------------
-template <int TW, int FF, typename Args>
-__device__ __forceinline__ void conv16_tile_q(const Args &a, const float *P, int mt, int i16, int g,
+// in GEMM-operand form: q[s] of lane (pixel i16, quarter g) = Q[pixel][ci = 4s + g] ------------------
+template <int TW, int FF>
+__device__ __forceinline__ void conv16_tile_q(const float *P, const float (&wcr)[9 * (FF / 4)],
+                                              const float (&cs)[4], const float (&ct)[4],
+                                              const float (&ca)[4], int mt, int i16, int g,
                                               float (&q)[4])
 {
     constexpr int PS = FF + 2, HW2 = TW + 2, KF = FF / 4;
     const int t = mt * 16 + i16;
     const int r_ = t / TW, c_ = t - r_ * TW;
-    const bool cval = i16 < FF;
-    const int ic = cval ? i16 : 0;
     f32x4 acc = {0};
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int kh = tap / 3, kw = tap - 3 * kh;
         const float *pq = P + ((r_ + kh) * HW2 + (c_ + kw)) * PS + g;
-        const float *wt = a.wc + (tap * FF + g) * FF + ic;
 #pragma unroll
-        for (int s = 0; s < KF; ++s) {  // ci = 4s + g: ascending across the lane quarters
-            const float w = wt[(4 * s) * FF];
-            acc = mfma16(cval ? w : 0.0f, pq[4 * s], acc);
-        }
+        for (int s = 0; s < KF; ++s)  // ci = 4s + g: ascending across the lane quarters
+            acc = mfma16(wcr[tap * KF + s], pq[4 * s], acc);
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)  // row 4g + r = output channel; rows >= FF carry cs = ct = 0 -> exact 0
+        q[r] = prelu1(fmaf(acc[r], cs[r], ct[r]), ca[r]);
+    transpose4(q[0], q[1], q[2], q[3]);
+}
+
+// BN + PReLU constants of the conv for the rows (channels 4g + r) this lane holds; 0 beyond FF
+template <int FF, typename Args>
+__device__ __forceinline__ void load_conv16_bn(const Args &a, int g, float (&cs)[4], float (&ct)[4],
+                                               float (&ca)[4])
+{
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int co = 4 * g + r;
         const bool ok = co < FF;
         const int cc = ok ? co : 0;
-        const float v = prelu1(fmaf(acc[r], a.cs[cc], a.ct[cc]), a.ca[cc]);
-        q[r] = ok ? v : 0.0f;
+        const float s_ = a.cs[cc], t_ = a.ct[cc], a_ = a.ca[cc];
+        cs[r] = ok ? s_ : 0.0f;
+        ct[r] = ok ? t_ : 0.0f;
+        ca[r] = ok ? a_ : 0.0f;
     }
-    transpose4(q[0], q[1], q[2], q[3]);
 }
 
 // =================================================================================================
 // regular / dilated bottleneck, CC channels, width FF = CC/4   (Bottleneck.call, enet_modules.py:526-599)
+// The expansion GEMM is evaluated as D[co][pixel] = We^T[co][ci] * Q[ci][pixel]: lane = pixel and the
+// 4 registers are 4 CONSECUTIVE output channels, so the residual read and the output write are one
+// float4 per lane and N-tile (16 B x 64 lanes per instruction instead of 4 B).
 // =================================================================================================
 template <int TW, int CC, int FF>
 __global__ __launch_bounds__(256, 4) void k_bottleneck16(BnkArgs a)
@@ -135,39 +164,54 @@ __global__ __launch_bounds__(256, 4) void k_bottleneck16(BnkArgs a)
     const float *ximg = a.x + (long)n * a.H * a.W * CC;
     float *yimg = a.y + (long)n * a.H * a.W * CC;
 
-    proj16_to_lds<TW, CC, FF>(a, ximg, P, TH, ty0, tx0, py, px, Hp, Wp, wave, i16, g);
+    if (a.ablate != 2)
+        proj16_to_lds<TW, CC, FF>(a, ximg, P, TH, ty0, tx0, py, px, Hp, Wp, wave, i16, g);
+
+    // loop-invariant operands of phase B, requested before the barrier so their latency overlaps it
+    float wcr[9 * KF];
+    load_conv16_weights<FF>(a, i16, g, wcr);
+    float cs[4], ct[4], ca[4];
+    load_conv16_bn<FF>(a, g, cs, ct, ca);
+    float wer[NT * KF];  // We^T as A operand: row = co_local (i16), k = ci = 4s + g
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int s = 0; s < KF; ++s) wer[nt * KF + s] = a.we[(4 * s + g) * CC + nt * 16 + i16];
+
     __syncthreads();
+    if (a.ablate == 1) return;
 
     const int nmt_out = (TH * TW) / 16;
     for (int mt = wave; mt < nmt_out; mt += 4) {
-        float q[4];
-        conv16_tile_q<TW, FF>(a, P, mt, i16, g, q);
-        int off[4];
-        unsigned okmask = 0;
+        // this lane's pixel and its residual / output address
+        const int t = mt * 16 + i16;
+        const int rr = t / TW, cc = t - rr * TW;
+        const int pr = ty0 + rr, pc = tx0 + cc;
+        const bool ok = (pr < Hp) && (pc < Wp);
+        const int off = ok ? ((py + pr * d) * a.W + (px + pc * d)) * CC + 4 * g : 4 * g;
+        float4 rx[NT];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ti = mt * 16 + 4 * g + r;
-            const int rr = ti / TW, cc = ti - rr * TW;
-            const int pr = ty0 + rr, pc = tx0 + cc;
-            const bool ok = (pr < Hp) && (pc < Wp);
-            okmask |= ok ? (1u << r) : 0u;
-            off[r] = ok ? ((py + pr * d) * a.W + (px + pc * d)) * CC : 0;
-        }
+        for (int nt = 0; nt < NT; ++nt)  // all residual fragments of the tile in flight during the conv
+            rx[nt] = *reinterpret_cast<const float4 *>(ximg + off + nt * 16);
+
+        float q[4];
+        conv16_tile_q<TW, FF>(P, wcr, cs, ct, ca, mt, i16, g, q);
+
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int co = nt * 16 + i16;
-            float rx[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rx[r] = ximg[off[r] + co];
             f32x4 e = {0};
 #pragma unroll
-            for (int s = 0; s < KF; ++s) e = mfma16(q[s], a.we[(4 * s + g) * CC + co], e);
-            const float s1 = a.es[co], t1 = a.et[co], al = a.ra[co];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = prelu1(fmaf(e[r], s1, t1) + rx[r], al);
-                if ((okmask >> r) & 1u) yimg[off[r] + co] = v;
-            }
+            for (int s = 0; s < KF; ++s) e = mfma16(wer[nt * KF + s], q[s], e);
+            const int co = nt * 16 + 4 * g;  // reg r = channel co + r
+            const float4 s1 = *reinterpret_cast<const float4 *>(a.es + co);
+            const float4 t1 = *reinterpret_cast<const float4 *>(a.et + co);
+            const float4 al = *reinterpret_cast<const float4 *>(a.ra + co);
+            float4 o;
+            o.x = prelu1(fmaf(e[0], s1.x, t1.x) + rx[nt].x, al.x);
+            o.y = prelu1(fmaf(e[1], s1.y, t1.y) + rx[nt].y, al.y);
+            o.z = prelu1(fmaf(e[2], s1.z, t1.z) + rx[nt].z, al.z);
+            o.w = prelu1(fmaf(e[3], s1.w, t1.w) + rx[nt].w, al.w);
+            if (ok) *reinterpret_cast<float4 *>(yimg + off + nt * 16) = o;
         }
     }
 }
@@ -247,10 +291,14 @@ __global__ __launch_bounds__(256, 4) void k_downsample16(DownArgs a)
     __syncthreads();
 
     // ---- phase B: 3x3 conv (8 -> 8), expansion (8 -> 64), pooled residual + codes -------------------
+    float wcr[9 * (FF / 4)];
+    load_conv16_weights<FF>(a, i16, g, wcr);
+    float cs[4], ct[4], ca[4];
+    load_conv16_bn<FF>(a, g, cs, ct, ca);
     const int nmt_out = (TH * TW) / 16;
     for (int mt = wave; mt < nmt_out; mt += 4) {
         float q[4];
-        conv16_tile_q<TW, FF>(a, P, mt, i16, g, q);
+        conv16_tile_q<TW, FF>(P, wcr, cs, ct, ca, mt, i16, g, q);
         int ooff[4], xoff[4];
         unsigned okmask = 0;
 #pragma unroll

@@ -143,6 +143,10 @@ int ssal_set_kernel_family(int use_mfma);
  * semantics): writes 256 floats */
 int ssal_debug_probe(float *out_dev_256, void *stream);
 
+/* measurement aid: bare fp32 MFMA loop (shape 32 = 32x32x2, 16 = 16x16x4), 4 waves per block, 4
+ * independent accumulators per wave; out_dev needs blocks*256 floats.  Time it with ssal_profile_*. */
+int ssal_debug_mfma_peak(int shape, int blocks, int iters, float *out_dev, void *stream);
+
 /* Measurement aid (no reference counterpart): when enabled, every kernel launch is bracketed by
  * HIP events on its own stream; ssal_profile_collect() returns per-kernel launch counts, total
  * milliseconds and ALGORITHMIC flops / bytes as a JSON object.  Single host thread only. */

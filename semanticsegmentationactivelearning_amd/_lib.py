@@ -46,6 +46,7 @@ PROTOTYPES = {
     "ssal_synth_frames_nhwc": (_i, [_c.c_uint64, _i64, _i, _i, _i, _i, _vp, _vp]),
     "ssal_set_kernel_family": (_i, [_i]),
     "ssal_debug_probe": (_i, [_vp, _vp]),
+    "ssal_debug_mfma_peak": (_i, [_i, _i, _i, _vp, _vp]),
     "ssal_profile_enable": (_i, [_i]),
     "ssal_profile_collect": (_i, [_c.c_char_p, _i64]),
 }

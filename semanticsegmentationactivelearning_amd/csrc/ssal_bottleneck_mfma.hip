@@ -141,36 +141,44 @@ __device__ __forceinline__ void conv_tile_q(const Args &a, const float *S, const
     const int t = mt * 32 + j;  // this lane's output pixel inside the tile (B operand)
     const int r = t / TW, c = t - r * TW;
     f32x16 acc = {0};
-    // software pipeline: the 16 weight fragments of tap t+1 are requested before the 16 MFMAs of
-    // tap t are issued, so their L2 latency hides behind ~1000 cycles of matrix work
-    float wcur[16];
-    {
-        const float *wt = wconv + (long)h * F + j;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) wcur[k] = wt[(2 * k) * F];  // W[0][ci = 2k + h][co = j]
-    }
-#pragma unroll 1
-    for (int tap = 0; tap < KH * KW; ++tap) {
+    // Software pipeline, one tap deep: while the 16 MFMAs of tap t run (~1000 cycles), the 16 weight
+    // fragments (L2) and the 8 activation fragments (LDS) of tap t+1 are already in flight.  Two
+    // static register buffers (A/B) alternate inside a loop over tap PAIRS; sched_barrier(0) keeps
+    // the compiler from sinking the loads next to their uses.
+    constexpr int NTAP = KH * KW;  // 9 or 5: odd
+    float wA[16], wB[16];
+    float2 pA[8], pB[8];
+    auto load_tap = [&](int tap, float (&w)[16], float2 (&p)[8]) {
         const int kh = tap / KW, kw = tap - KW * kh;
-        const int tn = tap + 1 < KH * KW ? tap + 1 : tap;
-        float wnxt[16];
-        {
-            const float *wt = wconv + (long)(tn * F + h) * F + j;
+        const float *wt = wconv + (long)(tap * F + h) * F + j;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) wnxt[k] = wt[(2 * k) * F];
-        }
+        for (int k = 0; k < 16; ++k) w[k] = wt[(2 * k) * F];  // W[tap][ci = 2k + h][co = j]
         const float *pq = S + ((r + kh) * SW + (c + kw)) * PSTR + 2 * h;
 #pragma unroll
-        for (int sq = 0; sq < 8; ++sq) {
-            float2 pv = *reinterpret_cast<const float2 *>(pq + 4 * sq);
-            float b0 = pv.x, b1 = pv.y;
-            swap32(b0, b1);  // b0 = ci(4sq | 4sq+1), b1 = ci(4sq+2 | 4sq+3)
-            acc = mfma32(wcur[2 * sq], b0, acc);      // W[tap][ci = 4sq + h][co = j]
-            acc = mfma32(wcur[2 * sq + 1], b1, acc);  // W[tap][ci = 4sq + 2 + h][co = j]
-        }
+        for (int sq = 0; sq < 8; ++sq) p[sq] = *reinterpret_cast<const float2 *>(pq + 4 * sq);
+    };
+    auto run_tap = [&](const float (&w)[16], const float2 (&p)[8]) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) wcur[k] = wnxt[k];
+        for (int sq = 0; sq < 8; ++sq) {
+            float b0 = p[sq].x, b1 = p[sq].y;
+            swap32(b0, b1);  // b0 = ci(4sq | 4sq+1), b1 = ci(4sq+2 | 4sq+3)
+            acc = mfma32(w[2 * sq], b0, acc);      // W[tap][ci = 4sq + h][co = j]
+            acc = mfma32(w[2 * sq + 1], b1, acc);  // W[tap][ci = 4sq + 2 + h][co = j]
+        }
+    };
+    load_tap(0, wA, pA);
+#pragma unroll 1
+    for (int tp = 0; tp + 1 < NTAP; tp += 2) {
+        load_tap(tp + 1, wB, pB);
+        __builtin_amdgcn_sched_barrier(0);
+        run_tap(wA, pA);
+        __builtin_amdgcn_sched_barrier(0);
+        load_tap(tp + 2, wA, pA);  // tp + 2 <= NTAP - 1 because NTAP is odd
+        __builtin_amdgcn_sched_barrier(0);
+        run_tap(wB, pB);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    run_tap(wA, pA);  // the last (odd) tap
     // conv epilogue: rows = co (registers), cols = pixel (lanes)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -226,6 +234,7 @@ __device__ __forceinline__ void conv_exp_store(const BnkArgs &a, const float *xi
 #pragma unroll
             for (int i = 0; i < 16; ++i) rxnxt[i] = ximg[off[i] + con];
             const float s1n = a.es[con], t1n = a.et[con], aln = a.ra[con];
+            __builtin_amdgcn_sched_barrier(0);  // keep the next N-tile's loads ahead of this MFMA chain
             f32x16 e = {0};
 #pragma unroll
             for (int s = 0; s < 16; ++s) e = mfma32(qv[ord(s)], wecur[s], e);
@@ -234,6 +243,7 @@ __device__ __forceinline__ void conv_exp_store(const BnkArgs &a, const float *xi
                 const float v = prelu1(fmaf(e[i], s1, t1) + rxcur[i], al);
                 if ((okmask >> i) & 1u) yimg[off[i] + co] = v;
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < 16; ++k) { wecur[k] = wenxt[k]; rxcur[k] = rxnxt[k]; }
             s1 = s1n; t1 = t1n; al = aln;
@@ -617,6 +627,57 @@ __global__ void k_probe_swap(float *out)
     swap16(c, e);
     out[128 + threadIdx.x] = c;
     out[192 + threadIdx.x] = e;
+}
+
+// ---- measurement aid: what the fp32 matrix pipe of THIS device sustains (bare dependent-free MFMA
+// loop, operands in registers, 4 accumulators per wave, 1 or 2 waves per SIMD) -------------------------
+// SHAPE 32 / 16: four independent accumulators; SHAPE 132: ONE dependent 32x32x2 chain per wave;
+// SHAPE 232: one dependent chain with a v_permlane32_swap feeding every MFMA pair (the conv loop shape)
+template <int SHAPE>
+__global__ __launch_bounds__(256) void k_mfma_peak(float *out, int iters)
+{
+    float a = 1.0f + 1e-3f * threadIdx.x, b = 0.999f;
+    if (SHAPE == 32) {
+        f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+        for (int i = 0; i < iters; ++i) {
+            c0 = mfma32(a, b, c0); c1 = mfma32(a, b, c1); c2 = mfma32(a, b, c2); c3 = mfma32(a, b, c3);
+        }
+        out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
+    } else if (SHAPE == 132) {
+        f32x16 c0 = {0};
+        for (int i = 0; i < iters; ++i) {
+            c0 = mfma32(a, b, c0); c0 = mfma32(b, a, c0); c0 = mfma32(a, b, c0); c0 = mfma32(b, a, c0);
+        }
+        out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c0[5];
+    } else if (SHAPE == 232) {
+        f32x16 c0 = {0};
+        float p = a, q = b;
+        for (int i = 0; i < iters; ++i) {
+            swap32(p, q); c0 = mfma32(a, p, c0); c0 = mfma32(b, q, c0);
+            swap32(p, q); c0 = mfma32(a, p, c0); c0 = mfma32(b, q, c0);
+        }
+        out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c0[5];
+    } else {
+        f32x4 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+        for (int i = 0; i < iters; ++i) {
+            c0 = mfma16(a, b, c0); c1 = mfma16(a, b, c1); c2 = mfma16(a, b, c2); c3 = mfma16(a, b, c3);
+        }
+        out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
+    }
+}
+
+hipError_t launch_mfma_peak(int shape, int blocks, int iters, float *out, hipStream_t s)
+{
+    const bool is32 = shape != 16;
+    const double flop = (double)blocks * 4 /*waves*/ * iters * 4.0 * (is32 ? 4096.0 : 2048.0);
+    const char *nm = shape == 32 ? "k_mfma_peak<32x32x2 4acc>" : shape == 132 ? "k_mfma_peak<32x32x2 1chain>"
+                   : shape == 232 ? "k_mfma_peak<32x32x2 1chain+swap>" : "k_mfma_peak<16x16x4 4acc>";
+    ProfScope prof(nm, flop, 0.0, s);
+    if (shape == 32) hipLaunchKernelGGL(k_mfma_peak<32>, dim3(blocks), dim3(256), 0, s, out, iters);
+    else if (shape == 132) hipLaunchKernelGGL(k_mfma_peak<132>, dim3(blocks), dim3(256), 0, s, out, iters);
+    else if (shape == 232) hipLaunchKernelGGL(k_mfma_peak<232>, dim3(blocks), dim3(256), 0, s, out, iters);
+    else hipLaunchKernelGGL(k_mfma_peak<16>, dim3(blocks), dim3(256), 0, s, out, iters);
+    return hipGetLastError();
 }
 
 hipError_t launch_probe_swap(float *out, hipStream_t s)

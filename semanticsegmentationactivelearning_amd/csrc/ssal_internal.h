@@ -92,6 +92,7 @@ hipError_t launch_upsample_mfma(const float *x, float *y, const uint8_t *code, i
                                 const float *we, const float *es, const float *et, const float *wr,
                                 const float *ra, hipStream_t s);
 hipError_t launch_probe_swap(float *out, hipStream_t s);
+hipError_t launch_mfma_peak(int shape, int blocks, int iters, float *out, hipStream_t s);
 
 hipError_t launch_prelu(const float *x, int64_t pixels, int C, const float *alpha, float *y,
                         hipStream_t s);

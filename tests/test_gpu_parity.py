@@ -448,3 +448,30 @@ def test_full_resolution_image_bit_exact(enet_c3k19):
     want_mean, _, want_label = orc.score_logits(want, "entropy")
     report_diff("1024x2048 label", extra["label"].cpu().numpy(), want_label)
     report_diff("1024x2048 mean", scores.cpu().numpy(), want_mean, exact=False, atol=1e-6)
+
+
+def test_rank_confidence_from_tfrecords(enet_c3k19, tmp_path):
+    """end-to-end front-end -> GPU: one PNG example per .tfrecord, decoded by tensortools.InputStage (the
+    reference's train/rank path with the (labelled, index) side channels), scored on the GPU, ranked"""
+    from test_input_cpu import write_pool
+    from semanticsegmentationactivelearning_amd.tensortools import InputStage, NumpyCapsule
+    net, P = enet_c3k19
+    num, k = 9, 2
+    files = write_pool(str(tmp_path), num, 64, 64, with_label=False)
+    cap = NumpyCapsule(shuffle=True, seed=5)
+    cap.filenames, cap.indices = files, np.arange(num)
+    cap.labelled = np.zeros(num, dtype=bool)
+    stage = InputStage(input_shape=[64, 64], seed=6)
+    stage.add_dataset_from_placeholders("train", cap.filenames, cap.labelled, cap.indices, batch_size=4)
+    stage.init_iterator("train", None, cap.feed_dict)  # eval-style decode: centre crop == identity, no flip
+
+    def batches():
+        for image, label, mask, labelled, index in stage:
+            yield image, index
+
+    unlabelled = np.arange(num)
+    low, uc = al.rank_confidence(net, batches(), num, unlabelled, k, measure="margin")
+    want_scores = np.concatenate([orc.score_images(P, frames([i], 64, 64, 3), "margin")[0] for i in range(num)])
+    want_low, want_uc = orc.rank_lowest(want_scores, unlabelled, k)
+    assert set(low.tolist()) == set(want_low.tolist())
+    report_diff("unlabelled_confidence", uc, want_uc, exact=False, atol=1e-6)

@@ -1,0 +1,158 @@
+"""CPU tests of the TFRecord front-end (tensortools.tfrecord / tensortools.input): wire format,
+framing + CRC, decoding, centre crop, label fill, masks, batching with aux side channels, NumpyCapsule."""
+import io
+import os
+import struct
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from semanticsegmentationactivelearning_amd import synthetic as syn
+from semanticsegmentationactivelearning_amd.tensortools import InputStage, NumpyCapsule, generate_mask, tfrecord
+
+
+def _png(arr):
+    buf = io.BytesIO()
+    Image.fromarray(arr.squeeze() if arr.shape[-1] == 1 else arr).save(buf, format="PNG")
+    return buf.getvalue()
+
+
+def write_pool(tmp, n, h, w, with_label=True, nir=False):
+    """one example per <id>.tfrecord file, schema of the reference README.md:18-42"""
+    files = []
+    for i in range(n):
+        img = syn.synth_frame_u8(i, h, w, 3)
+        feats = {"image/data": _png(img), "image/encoding": "png", "image/channels": 3,
+                 "height": h, "width": w, "id": "frame_%04d" % i}
+        if with_label and i % 2 == 0:
+            lab = (syn.synth_frame_u8(1000 + i, h, w, 1) % 20).astype(np.uint8)
+            lab[:2, :2, 0] = 255
+            feats["label"] = _png(lab)
+        else:
+            feats["label"] = b""
+        if nir:
+            feats["nir/data"] = _png(syn.synth_frame_u8(5000 + i, h, w, 1))
+            feats["nir/encoding"], feats["nir/channels"] = "png", 1
+        path = os.path.join(tmp, "frame_%04d.tfrecord" % i)
+        tfrecord.write_tfrecord(path, [tfrecord.make_example(feats)])
+        files.append(path)
+    return np.array(files)
+
+
+def test_crc32c_known_answers():
+    # RFC 3720 / iSCSI test vectors
+    assert tfrecord.crc32c(b"123456789") == 0xE3069283
+    assert tfrecord.crc32c(bytes(32)) == 0x8A9136AA
+    assert tfrecord.crc32c(bytes([0xFF] * 32)) == 0x62A8AB43
+
+
+def test_example_wire_roundtrip_and_framing(tmp_path):
+    ex = tfrecord.make_example({"image/data": b"\x00\x01\xff" * 50, "height": 1024, "width": -7, "id": "abc",
+                                "scores": [0.5, 1.25], "many": [1, 2, 300000000000]})
+    d = tfrecord.parse_example(ex)
+    assert d["image/data"] == ("bytes_list", [b"\x00\x01\xff" * 50])
+    assert d["height"] == ("int64_list", [1024]) and d["width"] == ("int64_list", [-7])
+    assert d["id"] == ("bytes_list", [b"abc"]) and d["many"][1] == [1, 2, 300000000000]
+    assert d["scores"][0] == "float_list" and np.allclose(d["scores"][1], [0.5, 1.25])
+    p = str(tmp_path / "two.tfrecord")
+    tfrecord.write_tfrecord(p, [ex, b"second"])
+    assert list(tfrecord.tfrecord_iterator(p, check_crc=True)) == [ex, b"second"]
+    assert tfrecord.read_tfrecord(p) == ex
+    raw = bytearray(open(p, "rb").read())
+    assert struct.unpack("<Q", raw[:8])[0] == len(ex)
+    raw[20] ^= 0xFF  # corrupt payload: only detected when CRC checking is on (the reference skips it)
+    open(p, "wb").write(raw)
+    assert len(list(tfrecord.tfrecord_iterator(p))) == 2
+    with pytest.raises(ValueError, match="CRC"):
+        list(tfrecord.tfrecord_iterator(p, check_crc=True))
+    fmt = tfrecord.parse_single_example(ex, {"height": -1, "missing": -1, "label": b""})
+    assert fmt == {"height": 1024, "missing": -1, "label": b""}
+    e = str(tmp_path / "empty.tfrecord")
+    open(e, "wb").close()
+    assert tfrecord.read_tfrecord(e) == b""
+
+
+def test_generate_mask():
+    lab = np.array([[[3], [255]], [[0], [7]]], np.uint8)
+    out, mask = generate_mask(lab)
+    assert out.tolist() == [[3, 0], [0, 7]] and mask.tolist() == [[1, 0], [1, 1]]
+
+
+def test_eval_path_center_crop_labels_and_partial_batch(tmp_path):
+    files = write_pool(str(tmp_path), 5, 40, 56)
+    stage = InputStage(input_shape=[32, 48])
+    n = stage.add_dataset("val", str(tmp_path), batch_size=2)
+    assert n == 5
+    stage.init_iterator("val")
+    batches = list(stage)
+    assert [b[0].shape[0] for b in batches] == [2, 2, 1]  # no drop_remainder (reference :193-194)
+    img, lab, mask = batches[0]
+    assert img.dtype == np.float32 and img.shape == (2, 32, 48, 3) and lab.shape == (2, 32, 48)
+    want = syn.u8_to_f32(syn.synth_frame_u8(0, 40, 56, 3))[4:36, 4:52]  # centre crop: 20-16=4, 28-24=4
+    assert (img[0] == want).all()
+    # example 1 has no label: 255-filled plane -> mask 0, label 0 everywhere
+    assert mask[1].sum() == 0 and lab[1].sum() == 0
+    assert mask[0].sum() > 0
+    with pytest.raises(StopIteration):
+        stage.get_output()
+
+
+def test_rank_path_aux_channels_and_capsule_feed(tmp_path):
+    files = write_pool(str(tmp_path), 6, 32, 32, with_label=False)
+    cap = NumpyCapsule(shuffle=True, seed=0)
+    cap.filenames = files
+    cap.labelled = np.array([True, False, True, False, False, False])
+    cap.indices = np.arange(6)
+    assert cap.size == 6
+    stage = InputStage(input_shape=[32, 32], seed=1)
+    stage.add_dataset_from_placeholders("train", cap.filenames, cap.labelled, cap.indices, batch_size=4, augment=True)
+    stage.init_iterator("train", None, cap.feed_dict)
+    seen = []
+    while True:
+        try:
+            image, image_dist, label, mask, labelled, index = stage.get_output()
+        except StopIteration:
+            break
+        assert image.shape[1:] == (32, 32, 3) and image_dist.shape == image.shape
+        assert (image_dist >= 0).all() and (image_dist <= 1).all()
+        for k, idx in enumerate(index):
+            ref = syn.u8_to_f32(syn.synth_frame_u8(int(idx), 32, 32, 3))
+            assert (image[k] == ref).all() or (image[k] == ref[:, ::-1]).all()  # crop is the identity, flip random
+            assert labelled[k] == cap.get_value("labelled")[idx]
+        seen.extend(index.tolist())
+    assert sorted(seen) == list(range(6)) and seen != list(range(6))  # one epoch, shuffled by the capsule
+
+
+def test_numpy_capsule_subsets_and_sampling():
+    cap = NumpyCapsule(shuffle=True, seed=3)
+    cap.values = np.arange(10) * 10
+    cap.set_indices(np.array([0, 1, 2]))
+    cap.set_sample_size(2)
+    assert cap.size == 5
+    fed = cap.feed_dict[cap.values]
+    assert len(fed) == 5 and {0, 10, 20} <= set(fed.tolist())
+    assert all(v >= 30 for v in set(fed.tolist()) - {0, 10, 20})
+    cap.set_indices()
+    assert cap.size == 10 and sorted(cap.feed_dict[cap.values].tolist()) == (np.arange(10) * 10).tolist()
+    cap.shuffle = False
+    assert cap.feed_dict[cap.values].tolist() == (np.arange(10) * 10).tolist()
+
+
+def test_modalities_rgb_nir(tmp_path):
+    write_pool(str(tmp_path), 2, 16, 16, nir=True)
+    stage = InputStage(input_shape=[16, 16], modalities=("nir",))
+    stage.add_dataset("test", str(tmp_path), batch_size=2)
+    stage.init_iterator("test")
+    img, lab, mask = stage.get_output()
+    assert img.shape == (2, 16, 16, 4)
+    assert (img[1, :, :, 3] == syn.u8_to_f32(syn.synth_frame_u8(5001, 16, 16, 1))[:, :, 0]).all()
+
+
+def test_too_small_example_is_an_error(tmp_path):
+    write_pool(str(tmp_path), 1, 16, 16)
+    stage = InputStage(input_shape=[32, 32])
+    stage.add_dataset("x", str(tmp_path), batch_size=1)
+    stage.init_iterator("x")
+    with pytest.raises(ValueError, match="smaller"):
+        stage.get_output()

@@ -290,58 +290,71 @@ __global__ __launch_bounds__(256, 4) void k_downsample16(DownArgs a)
     }
     __syncthreads();
 
-    // ---- phase B: 3x3 conv (8 -> 8), expansion (8 -> 64), pooled residual + codes -------------------
+    // ---- phase B: 3x3 conv (8 -> 8), expansion (8 -> 64) as D[co][pixel] (lane = pixel, 4 consecutive
+    // channels per lane -> float4 I/O), pooled residual + packed window codes ----------------------
     float wcr[9 * (FF / 4)];
     load_conv16_weights<FF>(a, i16, g, wcr);
     float cs[4], ct[4], ca[4];
     load_conv16_bn<FF>(a, g, cs, ct, ca);
+    float wer[(CO / 16) * 2];  // We^T as A operand: row = co_local (i16), k = ci = 4s + g, s < 2
+#pragma unroll
+    for (int nt = 0; nt < CO / 16; ++nt) {
+        wer[nt * 2 + 0] = a.we[(0 + g) * CO + nt * 16 + i16];
+        wer[nt * 2 + 1] = a.we[(4 + g) * CO + nt * 16 + i16];
+    }
     const int nmt_out = (TH * TW) / 16;
     for (int mt = wave; mt < nmt_out; mt += 4) {
+        const int t = mt * 16 + i16;
+        const int rr = t / TW, cc = t - rr * TW;
+        const int oy = ty0 + rr, ox = tx0 + cc;
+        const bool ok = (oy < Ho) && (ox < Wo);
+        const long opix = ok ? (long)oy * Wo + ox : 0;
+        // pooled residual of channels 4g..4g+3 (N-tile 0): 2x2 window, first maximum wins
+        const float *w0 = ximg + (ok ? ((long)(2 * oy) * a.W + 2 * ox) * CI : 0) + 4 * g;
+        const float4 v00 = *reinterpret_cast<const float4 *>(w0);
+        const float4 v01 = *reinterpret_cast<const float4 *>(w0 + CI);
+        const float4 v10 = *reinterpret_cast<const float4 *>(w0 + (long)a.W * CI);
+        const float4 v11 = *reinterpret_cast<const float4 *>(w0 + (long)a.W * CI + CI);
+
         float q[4];
         conv16_tile_q<TW, FF>(P, wcr, cs, ct, ca, mt, i16, g, q);
-        int ooff[4], xoff[4];
-        unsigned okmask = 0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ti = mt * 16 + 4 * g + r;
-            const int rr = ti / TW, cc = ti - rr * TW;
-            const int oy = ty0 + rr, ox = tx0 + cc;
-            const bool ok = (oy < Ho) && (ox < Wo);
-            okmask |= ok ? (1u << r) : 0u;
-            ooff[r] = ok ? oy * Wo + ox : 0;
-            xoff[r] = ok ? ((2 * oy) * a.W + 2 * ox) * CI : 0;
-        }
-#pragma unroll
-        for (int nt = 0; nt < CO / 16; ++nt) {
-            const int co = nt * 16 + i16;
-            float rx[4];
-            if (nt == 0) {  // channels < 16 carry the pooled block input (first maximum wins)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float *w0 = ximg + xoff[r] + co;
-                    const float v00 = w0[0], v01 = w0[CI];
-                    const float v10 = w0[(long)a.W * CI], v11 = w0[(long)a.W * CI + CI];
-                    float best = v00;
-                    int cd = 0;
-                    if (v01 > best) { best = v01; cd = 1; }
-                    if (v10 > best) { best = v10; cd = 2; }
-                    if (v11 > best) { best = v11; cd = 3; }
-                    rx[r] = best;
-                    if ((okmask >> r) & 1u) cimg[ooff[r] * CI + co] = (uint8_t)cd;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) rx[r] = 0.0f;
-            }
-            f32x4 e = {0};
-            e = mfma16(q[0], a.we[(0 + g) * CO + co], e);
-            e = mfma16(q[1], a.we[(4 + g) * CO + co], e);
-            const float s1 = a.es[co], t1 = a.et[co], al = a.ra[co];
+
+        float4 rx;
+        unsigned packed = 0;
+        {
+            const float c00[4] = {v00.x, v00.y, v00.z, v00.w}, c01[4] = {v01.x, v01.y, v01.z, v01.w};
+            const float c10[4] = {v10.x, v10.y, v10.z, v10.w}, c11[4] = {v11.x, v11.y, v11.z, v11.w};
+            float best[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = prelu1(fmaf(e[r], s1, t1) + rx[r], al);
-                if ((okmask >> r) & 1u) yimg[(long)ooff[r] * CO + co] = v;
+                float bv = c00[r];
+                unsigned cd = 0;
+                if (c01[r] > bv) { bv = c01[r]; cd = 1; }
+                if (c10[r] > bv) { bv = c10[r]; cd = 2; }
+                if (c11[r] > bv) { bv = c11[r]; cd = 3; }
+                best[r] = bv;
+                packed |= cd << (8 * r);
             }
+            rx = make_float4(best[0], best[1], best[2], best[3]);
+        }
+        if (ok) *reinterpret_cast<unsigned *>(cimg + opix * CI + 4 * g) = packed;  // 4 codes, channels 4g..4g+3
+
+#pragma unroll
+        for (int nt = 0; nt < CO / 16; ++nt) {
+            f32x4 e = {0};
+            e = mfma16(wer[nt * 2 + 0], q[0], e);
+            e = mfma16(wer[nt * 2 + 1], q[1], e);
+            const int co = nt * 16 + 4 * g;  // reg r = channel co + r
+            const float4 s1 = *reinterpret_cast<const float4 *>(a.es + co);
+            const float4 t1 = *reinterpret_cast<const float4 *>(a.et + co);
+            const float4 al = *reinterpret_cast<const float4 *>(a.ra + co);
+            const float4 rr4 = nt == 0 ? rx : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 o;
+            o.x = prelu1(fmaf(e[0], s1.x, t1.x) + rr4.x, al.x);
+            o.y = prelu1(fmaf(e[1], s1.y, t1.y) + rr4.y, al.y);
+            o.z = prelu1(fmaf(e[2], s1.z, t1.z) + rr4.z, al.z);
+            o.w = prelu1(fmaf(e[3], s1.w, t1.w) + rr4.w, al.w);
+            if (ok) *reinterpret_cast<float4 *>(yimg + opix * CO + co) = o;
         }
     }
 }
@@ -378,32 +391,42 @@ __global__ __launch_bounds__(256, 4) void k_upsample16(UpArgs a)
         const int co = 4 * (g & 1) + r;
         cs[r] = a.cs[co]; ct[r] = a.ct[co]; ca[r] = a.ca[co];
     }
-    const float s1 = a.es[i16], t1 = a.et[i16], al = a.ra[i16];
-    const float we0 = a.we[(0 + g) * CO + i16], we1 = a.we[(4 + g) * CO + i16];
+    // exp (8 -> 16) and residual conv (64 -> 16) are evaluated as D[co][pixel]: lane = pixel, reg r =
+    // channel 4g + r, so codes, residual and output are one 4-byte / 16-byte access per lane
+    const float4 s1 = *reinterpret_cast<const float4 *>(a.es + 4 * g);
+    const float4 t1 = *reinterpret_cast<const float4 *>(a.et + 4 * g);
+    const float4 al = *reinterpret_cast<const float4 *>(a.ra + 4 * g);
+    const float we0 = a.we[(0 + g) * CO + i16], we1 = a.we[(4 + g) * CO + i16];  // A: row co = i16
+    float wrr[16];  // Wr^T as A operand: row = co (i16), k = ci = 4s + g
+#pragma unroll
+    for (int s_ = 0; s_ < 16; ++s_) wrr[s_] = a.wr[(4 * s_ + g) * CO + i16];
 
     const int nmt = (TH * TW) / 16;
     for (int mt = wave; mt < nmt; mt += 4) {
         const int t = mt * 16 + i16;
         const int r_ = t / TW, c_ = t - r_ * TW;
-        const bool lane_ok = (ty0 + r_ < a.H) && (tx0 + c_ < a.W);
+        const int iy = ty0 + r_, ix = tx0 + c_;
+        const bool ok = (iy < a.H) && (ix < a.W);
+        const long ipix = ok ? (long)iy * a.W + ix : 0;
 
-        // ---- residual branch: D[pixel][co] = X[pixel][ci] * Wr[ci][co]  (64 -> 16) ------------------
+        // ---- residual branch: D[co][pixel] = Wr^T[co][ci] * X[ci][pixel]  (64 -> 16) -----------------
         f32x4 res = {0};
         {
-            const float *xp = lane_ok ? ximg + ((long)(ty0 + r_) * a.W + (tx0 + c_)) * CI : ximg;
+            const float *xp = ximg + ipix * CI;
             float4 v[4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) v[m] = *reinterpret_cast<const float4 *>(xp + 16 * m + 4 * g);
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 float r0 = v[m].x, r1 = v[m].y, r2 = v[m].z, r3 = v[m].w;
-                transpose4(r0, r1, r2, r3);
-                res = mfma16(r0, a.wr[(16 * m + 0 + g) * CO + i16], res);
-                res = mfma16(r1, a.wr[(16 * m + 4 + g) * CO + i16], res);
-                res = mfma16(r2, a.wr[(16 * m + 8 + g) * CO + i16], res);
-                res = mfma16(r3, a.wr[(16 * m + 12 + g) * CO + i16], res);
+                transpose4(r0, r1, r2, r3);  // reg r of quarter g: channel 16m + 4r + g
+                res = mfma16(wrr[4 * m + 0], r0, res);
+                res = mfma16(wrr[4 * m + 1], r1, res);
+                res = mfma16(wrr[4 * m + 2], r2, res);
+                res = mfma16(wrr[4 * m + 3], r3, res);
             }
         }
+        const unsigned codes = *reinterpret_cast<const unsigned *>(cimg + ipix * CO + 4 * g);
 
         // ---- transposed conv 16 -> 8: accA rows [ee|eo], accB rows [oe|oo] ---------------------------
         f32x4 accA = {0}, accB = {0};
@@ -413,9 +436,9 @@ __global__ __launch_bounds__(256, 4) void k_upsample16(UpArgs a)
             const float *pq = P + ((r_ + dr) * HW2 + (c_ + dc)) * PS + g;
             const float *wt = a.ws + (slot * PF + g) * 16 + i16;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                if (slot < 4) accA = mfma16(wt[(4 * s) * 16], pq[4 * s], accA);
-                else          accB = mfma16(wt[(4 * s) * 16], pq[4 * s], accB);
+            for (int s_ = 0; s_ < 4; ++s_) {
+                if (slot < 4) accA = mfma16(wt[(4 * s_) * 16], pq[4 * s_], accA);
+                else          accB = mfma16(wt[(4 * s_) * 16], pq[4 * s_], accB);
             }
         }
         float qa[4], qb[4];
@@ -428,35 +451,20 @@ __global__ __launch_bounds__(256, 4) void k_upsample16(UpArgs a)
         transpose4(qa[0], qa[1], qa[2], qa[3]);
         transpose4(qb[0], qb[1], qb[2], qb[3]);
 
-        int ooff[4], coff[4];
-        unsigned okmask = 0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ti = mt * 16 + 4 * g + r;
-            const int rr = ti / TW, cc = ti - rr * TW;
-            const int iy = ty0 + rr, ix = tx0 + cc;
-            const bool ok = (iy < a.H) && (ix < a.W);
-            okmask |= ok ? (1u << r) : 0u;
-            coff[r] = ok ? (iy * a.W + ix) * CO : 0;
-            ooff[r] = ok ? ((2 * iy) * (2 * a.W) + 2 * ix) * CO : 0;
-        }
-        int cd[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cd[r] = cimg[coff[r] + i16];
+        float *yp = yimg + (ok ? ((long)(2 * iy) * (2 * a.W) + 2 * ix) * CO : 0) + 4 * g;
 #pragma unroll
         for (int cls = 0; cls < 4; ++cls) {  // ee, eo, oe, oo == window code dy*2+dx
-            const float a0 = cls < 2 ? qa[(cls & 1) * 2] : qb[(cls & 1) * 2];
-            const float a1 = cls < 2 ? qa[(cls & 1) * 2 + 1] : qb[(cls & 1) * 2 + 1];
+            const float b0 = cls < 2 ? qa[(cls & 1) * 2] : qb[(cls & 1) * 2];
+            const float b1 = cls < 2 ? qa[(cls & 1) * 2 + 1] : qb[(cls & 1) * 2 + 1];
             f32x4 e = {0};
-            e = mfma16(a0, we0, e);
-            e = mfma16(a1, we1, e);
-            const int shift = ((cls >> 1) * (2 * a.W) + (cls & 1)) * CO;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float rsd = (cd[r] == cls) ? res[r] : 0.0f;
-                const float v = prelu1(fmaf(e[r], s1, t1) + rsd, al);
-                if ((okmask >> r) & 1u) yimg[ooff[r] + shift + i16] = v;
-            }
+            e = mfma16(we0, b0, e);
+            e = mfma16(we1, b1, e);
+            float4 o;
+            o.x = prelu1(fmaf(e[0], s1.x, t1.x) + (((codes >> 0) & 0xFFu) == (unsigned)cls ? res[0] : 0.0f), al.x);
+            o.y = prelu1(fmaf(e[1], s1.y, t1.y) + (((codes >> 8) & 0xFFu) == (unsigned)cls ? res[1] : 0.0f), al.y);
+            o.z = prelu1(fmaf(e[2], s1.z, t1.z) + (((codes >> 16) & 0xFFu) == (unsigned)cls ? res[2] : 0.0f), al.z);
+            o.w = prelu1(fmaf(e[3], s1.w, t1.w) + (((codes >> 24) & 0xFFu) == (unsigned)cls ? res[3] : 0.0f), al.w);
+            if (ok) *reinterpret_cast<float4 *>(yp + ((cls >> 1) * (2 * a.W) + (cls & 1)) * CO) = o;
         }
     }
     (void)CF;

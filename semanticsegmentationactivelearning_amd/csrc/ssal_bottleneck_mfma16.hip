@@ -139,13 +139,19 @@ __device__ __forceinline__ void load_conv16_bn(const Args &a, int g, float (&cs)
 // =================================================================================================
 // regular / dilated bottleneck, CC channels, width FF = CC/4   (Bottleneck.call, enet_modules.py:526-599)
 // The expansion GEMM is evaluated as D[co][pixel] = We^T[co][ci] * Q[ci][pixel]: lane = pixel and the
-// 4 registers are 4 CONSECUTIVE output channels, so the residual read and the output write are one
-// float4 per lane and N-tile (16 B x 64 lanes per instruction instead of 4 B).
+// 4 registers are 4 CONSECUTIVE output channels, so the residual and the output are one float4 per
+// lane and N-tile.  The residual is never re-read: phase A projects the tile's CENTRE pixels with the
+// same (wave, M-tile, lane) mapping phase B uses, and the float4 activation fragments it loads
+// (channels 16m + 4g .. +3 of the lane's pixel) are exactly the residual fragments of N-tile m, so they
+// stay in registers across the barrier; the one-pixel halo ring is projected separately.
 // =================================================================================================
 template <int TW, int CC, int FF>
-__global__ __launch_bounds__(256, 4) void k_bottleneck16(BnkArgs a)
+__global__ __launch_bounds__(256, 2) void k_bottleneck16(BnkArgs a)
 {
-    constexpr int PS = FF + 2, KF = FF / 4, NT = CC / 16;
+    constexpr int PS = FF + 2, KF = FF / 4, NT = CC / 16, HW2 = TW + 2, KP = CC / 4;
+    constexpr int TH = 8;                      // tile rows (launcher guarantees a.TH == 8)
+    constexpr int MPW = (TH * TW) / 16 / 4;    // centre M-tiles per wave: 4 (TW 32) or 2 (TW 16)
+    constexpr int RING = 2 * HW2 + 2 * TH;     // halo ring pixels: 84 or 52
     __shared__ float P[PMAX16 * PS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, g = lane >> 4;
@@ -158,14 +164,92 @@ __global__ __launch_bounds__(256, 4) void k_bottleneck16(BnkArgs a)
     const int n = b;
     const int Hp = (a.H - py + d - 1) / d;
     const int Wp = (a.W - px + d - 1) / d;
-    const int TH = a.TH;
     const int ty0 = ty * TH, tx0 = tx * TW;
     if (ty0 >= Hp || tx0 >= Wp) return;
     const float *ximg = a.x + (long)n * a.H * a.W * CC;
     float *yimg = a.y + (long)n * a.H * a.W * CC;
 
-    if (a.ablate != 2)
-        proj16_to_lds<TW, CC, FF>(a, ximg, P, TH, ty0, tx0, py, px, Hp, Wp, wave, i16, g);
+    // ---- phase A: projection of centre + ring into LDS -------------------------------------------
+    const bool cval = i16 < FF;
+    const int ic = cval ? i16 : 0;
+    float wpr[KP];
+#pragma unroll
+    for (int s = 0; s < KP; ++s) {
+        const float w = a.wp[(4 * s + g) * FF + ic];
+        wpr[s] = cval ? w : 0.0f;
+    }
+    const float bs = a.ps[ic], bt = a.pt[ic], ba = a.pa[ic];
+
+    // halo'd-tile index q of (a) centre pixel t, (b) ring pixel u
+    auto q_center = [&](int t) { return (t / TW + 1) * HW2 + (t % TW) + 1; };
+    auto q_ring = [&](int u) {
+        if (u < HW2) return u;
+        if (u < 2 * HW2) return (TH + 1) * HW2 + (u - HW2);
+        const int k = u - 2 * HW2;
+        return (1 + (k >> 1)) * HW2 + ((k & 1) ? HW2 - 1 : 0);
+    };
+    // project 16 pixels (one per i16; q < 0 = padding lane) and write the 16 results to P
+    auto project = [&](const float4 (&v)[NT], unsigned vmask, const int (&qrow)[4]) {
+        f32x4 acc = {0};
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+            float r0 = v[m].x, r1 = v[m].y, r2 = v[m].z, r3 = v[m].w;
+            transpose4(r0, r1, r2, r3);  // reg r of quarter g: channel 16m + 4r + g
+            acc = mfma16(r0, wpr[4 * m + 0], acc);
+            acc = mfma16(r1, wpr[4 * m + 1], acc);
+            acc = mfma16(r2, wpr[4 * m + 2], acc);
+            acc = mfma16(r3, wpr[4 * m + 3], acc);
+        }
+        if (cval) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = (vmask >> (4 * g + r)) & 1u;
+                if (qrow[r] >= 0) P[qrow[r] * PS + i16] = ok ? prelu1(fmaf(acc[r], bs, bt), ba) : 0.0f;
+            }
+        }
+    };
+
+    float4 xk[MPW][NT];  // centre activation fragments == residual fragments of phase B
+    int offk[MPW];       // element offset of the lane's pixel (+ 4g), -1 outside the image
+#pragma unroll
+    for (int k = 0; k < MPW; ++k) {
+        const int mt = wave + 4 * k;
+        const int t = mt * 16 + i16;
+        const int pr = ty0 + t / TW, pc = tx0 + t % TW;
+        const bool valid = (pr < Hp) && (pc < Wp);
+        offk[k] = valid ? ((py + pr * d) * a.W + (px + pc * d)) * CC + 4 * g : -1;
+        const float *xp = ximg + (valid ? offk[k] : 4 * g);
+#pragma unroll
+        for (int m = 0; m < NT; ++m) xk[k][m] = *reinterpret_cast<const float4 *>(xp + 16 * m);
+    }
+#pragma unroll
+    for (int k = 0; k < MPW; ++k) {
+        const int mt = wave + 4 * k;
+        const unsigned vmask = (unsigned)(__ballot(offk[k] >= 0) & 0xFFFFull);
+        int qrow[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) qrow[r] = q_center(mt * 16 + 4 * g + r);
+        if (a.ablate != 2) project(xk[k], vmask, qrow);
+    }
+    for (int mtr = wave; mtr * 16 < RING; mtr += 4) {  // halo ring
+        const int u = mtr * 16 + i16;
+        const int q = u < RING ? q_ring(u) : 0;
+        const int hr = q / HW2, hc = q - hr * HW2;
+        const int pr = ty0 - 1 + hr, pc = tx0 - 1 + hc;
+        const bool valid = (u < RING) && (pr >= 0) && (pr < Hp) && (pc >= 0) && (pc < Wp);
+        const unsigned vmask = (unsigned)(__ballot(valid) & 0xFFFFull);
+        int qrow[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ur = mtr * 16 + 4 * g + r;
+            qrow[r] = ur < RING ? q_ring(ur) : -1;
+        }
+        float4 v[NT];
+        const float *xp = valid ? ximg + ((long)(py + pr * d) * a.W + (px + pc * d)) * CC + 4 * g : ximg + 4 * g;
+#pragma unroll
+        for (int m = 0; m < NT; ++m) v[m] = *reinterpret_cast<const float4 *>(xp + 16 * m);
+        if (a.ablate != 2) project(v, vmask, qrow);
+    }
 
     // loop-invariant operands of phase B, requested before the barrier so their latency overlaps it
     float wcr[9 * KF];
@@ -181,22 +265,12 @@ __global__ __launch_bounds__(256, 4) void k_bottleneck16(BnkArgs a)
     __syncthreads();
     if (a.ablate == 1) return;
 
-    const int nmt_out = (TH * TW) / 16;
-    for (int mt = wave; mt < nmt_out; mt += 4) {
-        // this lane's pixel and its residual / output address
-        const int t = mt * 16 + i16;
-        const int rr = t / TW, cc = t - rr * TW;
-        const int pr = ty0 + rr, pc = tx0 + cc;
-        const bool ok = (pr < Hp) && (pc < Wp);
-        const int off = ok ? ((py + pr * d) * a.W + (px + pc * d)) * CC + 4 * g : 4 * g;
-        float4 rx[NT];
+    // ---- phase B: conv, expansion, residual (from registers), store -------------------------------
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)  // all residual fragments of the tile in flight during the conv
-            rx[nt] = *reinterpret_cast<const float4 *>(ximg + off + nt * 16);
-
+    for (int k = 0; k < MPW; ++k) {
+        const int mt = wave + 4 * k;
         float q[4];
         conv16_tile_q<TW, FF>(P, wcr, cs, ct, ca, mt, i16, g, q);
-
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             f32x4 e = {0};
@@ -207,11 +281,11 @@ __global__ __launch_bounds__(256, 4) void k_bottleneck16(BnkArgs a)
             const float4 t1 = *reinterpret_cast<const float4 *>(a.et + co);
             const float4 al = *reinterpret_cast<const float4 *>(a.ra + co);
             float4 o;
-            o.x = prelu1(fmaf(e[0], s1.x, t1.x) + rx[nt].x, al.x);
-            o.y = prelu1(fmaf(e[1], s1.y, t1.y) + rx[nt].y, al.y);
-            o.z = prelu1(fmaf(e[2], s1.z, t1.z) + rx[nt].z, al.z);
-            o.w = prelu1(fmaf(e[3], s1.w, t1.w) + rx[nt].w, al.w);
-            if (ok) *reinterpret_cast<float4 *>(yimg + off + nt * 16) = o;
+            o.x = prelu1(fmaf(e[0], s1.x, t1.x) + xk[k][nt].x, al.x);
+            o.y = prelu1(fmaf(e[1], s1.y, t1.y) + xk[k][nt].y, al.y);
+            o.z = prelu1(fmaf(e[2], s1.z, t1.z) + xk[k][nt].z, al.z);
+            o.w = prelu1(fmaf(e[3], s1.w, t1.w) + xk[k][nt].w, al.w);
+            if (offk[k] >= 0) *reinterpret_cast<float4 *>(yimg + offk[k] + nt * 16) = o;
         }
     }
 }

@@ -69,24 +69,23 @@ __device__ __forceinline__ void proj_to_lds(const Args &a, const float *ximg, fl
             continue;
         }
         const float *xp = valid ? ximg + ((long)(py + pr * d) * a.W + (px + pc * d)) * C : ximg;
+        // all 16 activation fragments of the M-tile are requested before the first MFMA (the compiler
+        // would otherwise serialise load-pair / wait / 8 MFMAs and expose the memory latency 8 times)
+        float4 X[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)  // lane half h takes the h-th float4 of every 8 channels
+            X[u] = *reinterpret_cast<const float4 *>(xp + (2 * u + h) * 4);
+        __builtin_amdgcn_sched_barrier(0);
         f32x16 acc = {0};
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {  // 32 input channels per chunk
-            float4 v[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m)  // lane half h takes the h-th float4 of every 8 channels
-                v[m] = *reinterpret_cast<const float4 *>(xp + kc * 32 + (2 * m + h) * 4);
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                float a0 = v[m].x, a1 = v[m].y, a2 = v[m].z, a3 = v[m].w;
-                swap32(a0, a1);  // a0 = ch(8m+0 | 8m+1), a1 = ch(8m+4 | 8m+5)
-                swap32(a2, a3);  // a2 = ch(8m+2 | 8m+3), a3 = ch(8m+6 | 8m+7)
-                const int s0 = kc * 16 + m * 4;
-                acc = mfma32(a0, wpr[s0 + 0], acc);
-                acc = mfma32(a2, wpr[s0 + 1], acc);
-                acc = mfma32(a1, wpr[s0 + 2], acc);
-                acc = mfma32(a3, wpr[s0 + 3], acc);
-            }
+        for (int u = 0; u < 16; ++u) {  // float4 u of half h = channels 8u + 4h .. 8u + 4h + 3
+            float a0 = X[u].x, a1 = X[u].y, a2 = X[u].z, a3 = X[u].w;
+            swap32(a0, a1);  // a0 = ch(8u+0 | 8u+1), a1 = ch(8u+4 | 8u+5)
+            swap32(a2, a3);  // a2 = ch(8u+2 | 8u+3), a3 = ch(8u+6 | 8u+7)
+            acc = mfma32(a0, wpr[4 * u + 0], acc);
+            acc = mfma32(a2, wpr[4 * u + 1], acc);
+            acc = mfma32(a1, wpr[4 * u + 2], acc);
+            acc = mfma32(a3, wpr[4 * u + 3], acc);
         }
         // epilogue: rows = pixels (registers), cols = co (lanes): BN + PReLU, zero padding
 #pragma unroll

@@ -528,7 +528,7 @@ hipError_t run_regular(const DevLayer &L, const float *x, int n, int h, int w, f
                        const LayerTemps &T, hipStream_t s)
 {
     const int C = L.cin, f = L.f;
-    if (g_use_mfma && (long)h * w * C < (1L << 31) && bottleneck_mfma_supported(C, f, L.asym))
+    if (g_use_mfma && (long)h * w * C <= (1L << 29) && bottleneck_mfma_supported(C, f, L.asym))
         return launch_bottleneck_mfma(x, y, n, h, w, C, L.dil, L.proj_w, L.proj_scale, L.proj_shift,
                                       L.proj_alpha, L.conv_w, L.asym ? L.conv_w1 : nullptr,
                                       L.conv_scale, L.conv_shift, L.conv_alpha, L.exp_w, L.exp_scale,

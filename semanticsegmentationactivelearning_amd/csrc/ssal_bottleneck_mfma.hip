@@ -199,54 +199,81 @@ __device__ __forceinline__ void conv_exp_store(const BnkArgs &a, const float *xi
 {
     const int d = a.dil;
     const int nmt_out = (TH * TW) / 32;
+    // raw buffer resources over image n of x and y (num_records = image bytes <= 2 GiB); kOOB is an
+    // offset the range check always rejects, even after the +384 B N-tile immediates
+    constexpr unsigned kOOB = 0x80000000u;
+    const unsigned img_bytes = (unsigned)(a.H * a.W * C) * 4u;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ximg), 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yimg, 0, img_bytes, 0x00020000);
     for (int mt = wave; mt < nmt_out; mt += 4) {
         float qv[16];
         conv_tile_q<TW, KH, KW, SW>(a, S, wconv, mt, j, h, qv);
 
-        // element offsets (inside image n) of the 16 output rows this lane-half stores
-        int off[16];
-        unsigned okmask = 0;
+        // BYTE offsets (inside image n) of the 16 output rows this lane-half stores, lane channel folded
+        // in.  Residual loads and output stores go through raw buffer instructions (uniform resource +
+        // 32-bit lane offset + immediate): no per-access address arithmetic, and rows outside the image
+        // get an out-of-range offset, so the hardware range check drops their stores / returns 0 for
+        // their loads -- no exec-mask branches in the epilogue.
+        unsigned boff[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int ti = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
             const int rr = ti / TW, cc = ti - rr * TW;
             const int pr = ty0 + rr, pc = tx0 + cc;
             const bool ok = (pr < Hp) && (pc < Wp);
-            okmask |= ok ? (1u << i) : 0u;
-            off[i] = ok ? ((py + pr * d) * a.W + (px + pc * d)) * C : 0;  // 0 = a safe address
+            boff[i] = ok ? (unsigned)((((py + pr * d) * a.W + (px + pc * d)) * C + j) * 4) : kOOB;
         }
-        // expansion: operands of N-tile nt+1 (16 weight fragments, 16 residual rows, 3 constants) are
-        // requested before the MFMA chain of N-tile nt runs
-        float wecur[16], rxcur[16];
-        float s1 = a.es[j], t1 = a.et[j], al = a.ra[j];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) wecur[k] = a.we[(2 * k + h) * C + j];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) rxcur[i] = ximg[off[i] + j];
-#pragma unroll 1
-        for (int nt = 0; nt < 4; ++nt) {
+        // Expansion, software-pipelined over the 4 N-tiles: the MFMA chain of N-tile nt+1 is issued
+        // interleaved with the epilogue (BN + residual + PReLU + store) of N-tile nt, so the epilogue
+        // executes in the shadow of 16 MFMAs (1024 cycles) instead of leaving the matrix pipe idle;
+        // operands of N-tile nt+2 are requested one stage ahead.
+        float weA[16], weB[16], rxA[16], rxB[16];
+        float sA, tA, aA, sB, tB, aB;
+        auto fetch = [&](int nt, float (&we)[16], float (&rx)[16], float &s1, float &t1, float &al) {
             const int co = nt * 32 + j;
-            const int con = (nt < 3 ? nt + 1 : nt) * 32 + j;
-            float wenxt[16], rxnxt[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) wenxt[k] = a.we[(2 * k + h) * C + con];
+            for (int k = 0; k < 16; ++k) we[k] = a.we[(2 * k + h) * C + co];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) rxnxt[i] = ximg[off[i] + con];
-            const float s1n = a.es[con], t1n = a.et[con], aln = a.ra[con];
-            __builtin_amdgcn_sched_barrier(0);  // keep the next N-tile's loads ahead of this MFMA chain
-            f32x16 e = {0};
+            for (int i = 0; i < 16; ++i)
+                rx[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, boff[i] + nt * 128, 0, 0));
+            s1 = a.es[co]; t1 = a.et[co]; al = a.ra[co];
+        };
+        auto put = [&](int nt, int i, float v) {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, boff[i] + nt * 128, 0, 0);
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(0, weA, rxA, sA, tA, aA);
+        fetch(1, weB, rxB, sB, tB, aB);
+        f32x16 e0 = {0}, e1 = {0};
 #pragma unroll
-            for (int s = 0; s < 16; ++s) e = mfma32(qv[ord(s)], wecur[s], e);
+        for (int s = 0; s < 16; ++s) e0 = mfma32(qv[ord(s)], weA[s], e0);  // N-tile 0
+        // stage 1: chain of N-tile 1  ||  epilogue of N-tile 0
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float v = prelu1(fmaf(e[i], s1, t1) + rxcur[i], al);
-                if ((okmask >> i) & 1u) yimg[off[i] + co] = v;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < 16; ++k) { wecur[k] = wenxt[k]; rxcur[k] = rxnxt[k]; }
-            s1 = s1n; t1 = t1n; al = aln;
+        for (int s = 0; s < 16; ++s) {
+            e1 = mfma32(qv[ord(s)], weB[s], e1);
+            put(0, s, prelu1(fmaf(e0[s], sA, tA) + rxA[s], aA));
         }
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(2, weA, rxA, sA, tA, aA);
+        e0 = (f32x16){0};
+        // stage 2: chain of N-tile 2  ||  epilogue of N-tile 1
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            e0 = mfma32(qv[ord(s)], weA[s], e0);
+            put(1, s, prelu1(fmaf(e1[s], sB, tB) + rxB[s], aB));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(3, weB, rxB, sB, tB, aB);
+        e1 = (f32x16){0};
+        // stage 3: chain of N-tile 3  ||  epilogue of N-tile 2
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            e1 = mfma32(qv[ord(s)], weB[s], e1);
+            put(2, s, prelu1(fmaf(e0[s], sA, tA) + rxA[s], aA));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) put(3, s, prelu1(fmaf(e1[s], sB, tB) + rxB[s], aB));
     }
 }
 

@@ -102,6 +102,16 @@ int ssal_score_logits_nhwc(const float *logits_dev, int n, int h, int w, int cla
                            uint8_t *mask_dev, float *conf_dev, void *ws_dev, int64_t ws_bytes,
                            void *stream);
 
+/* tensortools.losses.masked_softmax_cross_entropy forward (tensortools/losses.py:3-74): label
+ * smoothing, optional ENet-style class weighting (weight > 1), fp32 sum over the batch axis, float64
+ * over the spatial axes, divided by the (fp32) mask sum.  labels uint8 [n,h,w], mask fp32 [n,h,w],
+ * loss_dev: one float64. */
+int64_t ssal_xent_workspace_bytes(int h, int w);
+int ssal_masked_softmax_cross_entropy(const float *logits_dev, const uint8_t *labels_dev,
+                                      const float *mask_dev, int n, int h, int w, int classes,
+                                      float weight, float label_smoothing, double *loss_dev,
+                                      void *ws_dev, int64_t ws_bytes, void *stream);
+
 /* tf.nn.max_pool_with_argmax(ksize 2x2, strides 2, SAME, Targmax=int64) (enet_modules.py:927-929);
  * include_batch selects the TF<=1.13 CPU index convention (extra_ops.py:63-81). */
 int ssal_max_pool_with_argmax_2x2(const float *x_dev, int n, int h, int w, int c, float *y_dev,

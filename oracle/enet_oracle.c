@@ -269,3 +269,38 @@ ORC_API void orc_concat2(const float *a, int Ca, const float *b, int Cb, size_t 
         memcpy(y + p * (Ca + Cb) + Ca, b + p * Cb, sizeof(float) * Cb);
     }
 }
+
+/* tensortools.losses.masked_softmax_cross_entropy forward (reference tensortools/losses.py:3-74).
+ * fp32 per-pixel cross entropy with label smoothing, mask, optional class weighting (weight > 1),
+ * fp32 sum over the batch axis, float64 over the spatial axes, divided by (double)(float)sum(mask). */
+ORC_API double orc_masked_softmax_xent(const float *logits, const uint8_t *labels, const float *mask,
+                                       int N, int H, int W, int K, float weight, float label_smoothing)
+{
+    const float on_value = 1.0f - label_smoothing, off_value = label_smoothing / ((float)K - 1.0f);
+    size_t P = (size_t)H * W;
+    double total = 0.0;
+    float msum = 0.0f;
+    for (size_t i = 0; i < (size_t)N * P; ++i) msum += mask[i];
+    for (size_t pos = 0; pos < P; ++pos) {
+        float bsum = 0.0f;
+        for (int n = 0; n < N; ++n) {
+            const float *l = logits + ((size_t)n * P + pos) * K;
+            int lab = labels[(size_t)n * P + pos];
+            float m = l[0];
+            for (int k = 1; k < K; ++k) if (l[k] > m) m = l[k];
+            float S = 0.0f;
+            for (int k = 0; k < K; ++k) S += expf(l[k] - m);
+            float logS = logf(S), ce = 0.0f, pc = 0.0f;
+            for (int k = 0; k < K; ++k) {
+                float yk = (k == lab) ? on_value : off_value;
+                ce += yk * (logS - (l[k] - m));
+                pc += yk * (expf(l[k] - m) / S);
+            }
+            ce *= mask[(size_t)n * P + pos];
+            if (weight > 1.0f) ce *= 1.0f / logf(weight + (1.718281828459045f - weight) * pc);
+            bsum += ce;
+        }
+        total += (double)bsum;
+    }
+    return total / (double)msum;
+}

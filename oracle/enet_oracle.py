@@ -261,3 +261,17 @@ def rank_lowest(scores_f64_by_example, unlabelled, selection_size):
     if k >= len(uc):
         return unl.copy(), uc
     return unl[np.argpartition(uc, k)[:k]], uc
+
+
+def masked_softmax_cross_entropy(labels, logits, mask, num_classes, weight=0.0, label_smoothing=0.0):
+    """tensortools/losses.py:3-74 (forward value, float64)"""
+    lg = _f32(logits)
+    n, h, w, k = lg.shape
+    assert k == num_classes
+    lab = np.ascontiguousarray(np.asarray(labels).reshape(n, h, w), dtype=np.uint8)
+    mk = _f32(np.asarray(mask).reshape(n, h, w))
+    lib = _lib()
+    lib.orc_masked_softmax_xent.restype = ctypes.c_double
+    lib.orc_masked_softmax_xent.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float]
+    return float(lib.orc_masked_softmax_xent(_p(lg), _p(lab), _p(mk), n, h, w, k, weight, label_smoothing))

@@ -36,6 +36,8 @@ PROTOTYPES = {
     "ssal_enet_layer_workspace_bytes": (_i64, [_vp, _c.c_char_p, _i, _i, _i]),
     "ssal_score_workspace_bytes": (_i64, [_i, _i, _i]),
     "ssal_score_logits_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "ssal_xent_workspace_bytes": (_i64, [_i, _i]),
+    "ssal_masked_softmax_cross_entropy": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _i64, _vp]),
     "ssal_max_pool_with_argmax_2x2": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "ssal_unpool_2d": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ssal_prelu": (_i, [_vp, _i64, _i, _vp, _vp, _vp]),

@@ -887,6 +887,29 @@ SSAL_API int ssal_score_logits_nhwc(const float *logits_dev, int n, int h, int w
     return SSAL_OK;
 }
 
+SSAL_API int64_t ssal_xent_workspace_bytes(int h, int w)
+{
+    if (h <= 0 || w <= 0) return -1;
+    return (int64_t)xent_blocks(h, w) * 16 + 256;
+}
+
+SSAL_API int ssal_masked_softmax_cross_entropy(const float *logits_dev, const uint8_t *labels_dev,
+                                               const float *mask_dev, int n, int h, int w, int classes,
+                                               float weight, float label_smoothing, double *loss_dev,
+                                               void *ws_dev, int64_t ws_bytes, void *stream)
+{
+    if (!logits_dev || !labels_dev || !mask_dev || !loss_dev || !ws_dev) return fail(SSAL_EINVAL, "NULL device pointer");
+    if (n <= 0 || h <= 0 || w <= 0) return fail(SSAL_EINVAL, "bad dims n=%d h=%d w=%d", n, h, w);
+    if (classes < 2 || classes > 32) return fail(SSAL_EINVAL, "classes must be in [2,32] (got %d)", classes);
+    if (ws_bytes < ssal_xent_workspace_bytes(h, w))
+        return fail(SSAL_ENOMEM, "workspace too small: need %lld bytes", (long long)ssal_xent_workspace_bytes(h, w));
+    Bump b(ws_dev, ws_bytes);
+    double *partial = b.take<double>(2 * (int64_t)xent_blocks(h, w));
+    HIP_TRY(launch_masked_xent(logits_dev, labels_dev, mask_dev, n, h, w, classes, weight,
+                               label_smoothing, partial, loss_dev, (hipStream_t)stream));
+    return SSAL_OK;
+}
+
 SSAL_API int ssal_max_pool_with_argmax_2x2(const float *x_dev, int n, int h, int w, int c,
                                            float *y_dev, int64_t *argmax_dev, int include_batch,
                                            void *stream)

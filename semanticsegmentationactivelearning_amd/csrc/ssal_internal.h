@@ -60,6 +60,12 @@ hipError_t launch_score_logits(const float *logits, int N, int H, int W, int K, 
                                float threshold, double *partial, uint8_t *label, uint8_t *mask,
                                float *conf, hipStream_t s);
 
+// masked softmax cross-entropy forward (tensortools/losses.py:3-74); partial: 2 * xent_blocks doubles
+int xent_blocks(int H, int W);
+hipError_t launch_masked_xent(const float *logits, const uint8_t *labels, const float *mask, int N,
+                              int H, int W, int K, float weight, float label_smoothing,
+                              double *partial, double *out, hipStream_t s);
+
 // pooling / unpooling with reference int64 indices
 hipError_t launch_maxpool_argmax(const float *x, int N, int H, int W, int C, float *y,
                                  int64_t *argmax, int include_batch, hipStream_t s);

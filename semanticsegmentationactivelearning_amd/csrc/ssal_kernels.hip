@@ -573,6 +573,105 @@ hipError_t launch_score_logits(const float *logits, int N, int H, int W, int K, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// masked_softmax_cross_entropy forward (tensortools/losses.py:3-74):
+//   y_k = one_hot(label, K, on = 1 - ls, off = ls / (K - 1));   ce = sum_k y_k * (log S - (x_k - m))
+//   ce *= mask;  if weight > 1: ce *= 1 / log(weight + (1.718281828459045 - weight) * sum_k p_k y_k)
+//   loss = sum_pos (double)(sum_n ce[n,pos]) / (double)(float)(sum mask)      (fp32 over the batch axis,
+//   float64 over the spatial axes, :62-73).  Block partials + fixed-order final sum (reproducible).
+// ------------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void k_masked_xent(const float *__restrict__ logits,
+                                                     const uint8_t *__restrict__ labels,
+                                                     const float *__restrict__ mask, int N, long HW,
+                                                     float weight, float on_value, float off_value,
+                                                     double *__restrict__ partial)
+{
+    __shared__ double red[4];
+    const long pos = (long)blockIdx.x * 256 + threadIdx.x;
+    double loss = 0.0, msum = 0.0;
+    if (pos < HW) {
+        float bsum = 0.0f;  // tf.reduce_sum(loss, axis=0) in fp32
+        for (int n = 0; n < N; ++n) {
+            const float *l = logits + ((long)n * HW + pos) * K;
+            const int lab = labels[(long)n * HW + pos];
+            const float mk = mask[(long)n * HW + pos];
+            float x[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) x[k] = l[k];
+            float m = x[0];
+#pragma unroll
+            for (int k = 1; k < K; ++k) m = fmaxf(m, x[k]);
+            float S = 0.0f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) S += expf(x[k] - m);
+            const float logS = logf(S);
+            float ce = 0.0f, pc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float yk = (k == lab) ? on_value : off_value;
+                const float d = x[k] - m;
+                ce += yk * (logS - d);
+                pc += yk * (expf(d) / S);
+            }
+            ce *= mk;
+            if (weight > 1.0f) ce *= 1.0f / logf(weight + (1.718281828459045f - weight) * pc);
+            bsum += ce;
+            msum += (double)mk;
+        }
+        loss = (double)bsum;
+    }
+    const double r0 = block_sum_256(loss, red);
+    __syncthreads();
+    const double r1 = block_sum_256(msum, red);
+    if (threadIdx.x == 0) {
+        partial[2 * (long)blockIdx.x] = r0;
+        partial[2 * (long)blockIdx.x + 1] = r1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_xent_finish(const double *__restrict__ partial, int blocks,
+                                                     double *__restrict__ out)
+{
+    __shared__ double red[4];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < blocks; i += 256) { a += partial[2 * (long)i]; b += partial[2 * (long)i + 1]; }
+    const double ra = block_sum_256(a, red);
+    __syncthreads();
+    const double rb = block_sum_256(b, red);
+    if (threadIdx.x == 0) out[0] = ra / (double)(float)rb;  // tf.cast(tf.reduce_sum(_mask) [fp32], float64)
+}
+
+int xent_blocks(int H, int W) { return cdiv((long)H * W, 256); }
+
+hipError_t launch_masked_xent(const float *logits, const uint8_t *labels, const float *mask, int N,
+                              int H, int W, int K, float weight, float label_smoothing,
+                              double *partial, double *out, hipStream_t s)
+{
+    const long HW = (long)H * W;
+    const int blocks = xent_blocks(H, W);
+    const float on_value = 1.0f - label_smoothing, off_value = label_smoothing / ((float)K - 1.0f);
+#define SSAL_XE(KK)                                                                               \
+    case KK:                                                                                      \
+        hipLaunchKernelGGL(k_masked_xent<KK>, dim3(blocks), dim3(256), 0, s, logits, labels, mask, \
+                           N, HW, weight, on_value, off_value, partial);                          \
+        break;
+    switch (K) {
+        SSAL_XE(2) SSAL_XE(3) SSAL_XE(4) SSAL_XE(5) SSAL_XE(6) SSAL_XE(7) SSAL_XE(8) SSAL_XE(9)
+        SSAL_XE(10) SSAL_XE(11) SSAL_XE(12) SSAL_XE(13) SSAL_XE(14) SSAL_XE(15) SSAL_XE(16)
+        SSAL_XE(17) SSAL_XE(18) SSAL_XE(19) SSAL_XE(20) SSAL_XE(21) SSAL_XE(22) SSAL_XE(23)
+        SSAL_XE(24) SSAL_XE(25) SSAL_XE(26) SSAL_XE(27) SSAL_XE(28) SSAL_XE(29) SSAL_XE(30)
+        SSAL_XE(31) SSAL_XE(32)
+    default:
+        return hipErrorInvalidValue;
+    }
+#undef SSAL_XE
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_xent_finish, dim3(1), dim3(256), 0, s, partial, blocks, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // tf.nn.max_pool_with_argmax 2x2/s2 with the reference's int64 index and the scatter
 // form of xops.unpool_2d (extra_ops.py:28-86) for arbitrary index tensors.
 // ------------------------------------------------------------------------------------------------

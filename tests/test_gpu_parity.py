@@ -475,3 +475,50 @@ def test_rank_confidence_from_tfrecords(enet_c3k19, tmp_path):
     want_low, want_uc = orc.rank_lowest(want_scores, unlabelled, k)
     assert set(low.tolist()) == set(want_low.tolist())
     report_diff("unlabelled_confidence", uc, want_uc, exact=False, atol=1e-6)
+
+
+# ---- loss forward value, inference path ------------------------------------
+@pytest.mark.parametrize("weight,ls,k", [(0.0, 0.0, 19), (0.0, 0.05, 19), (1.5, 0.05, 19), (1.02, 0.1, 6)])
+def test_masked_softmax_cross_entropy_forward(weight, ls, k):
+    from semanticsegmentationactivelearning_amd.tensortools import losses
+    rng = np.random.default_rng(21)
+    lg = (rng.normal(size=(3, 12, 20, k)) * 3).astype(np.float32)
+    lab = rng.integers(0, k, size=(3, 12, 20)).astype(np.uint8)
+    mask = (rng.uniform(size=(3, 12, 20)) > 0.3).astype(np.float32)
+    want = orc.masked_softmax_cross_entropy(lab, lg, mask, k, weight, ls)
+    got = float(losses.masked_softmax_cross_entropy(dev(lab), dev(lg), dev(mask), k, weight, ls))
+    assert abs(got - want) <= 1e-5 * max(1.0, abs(want)), (got, want)
+    # literal float64 numpy statement of tensortools/losses.py:27-73
+    x = lg.astype(np.float64)
+    lse = np.log(np.exp(x - x.max(-1, keepdims=True)).sum(-1)) + x.max(-1)
+    oh = np.full(lg.shape, ls / (k - 1.0)); np.put_along_axis(oh, lab[..., None].astype(np.int64), 1.0 - ls, -1)
+    ce = (oh * (lse[..., None] - x)).sum(-1) * mask
+    if weight > 1.0:
+        p = (np.exp(x - lse[..., None]) * oh).sum(-1)
+        ce = ce / np.log(weight + (1.718281828459045 - weight) * p)
+    ref = ce.sum(0).sum() / mask.sum()
+    assert abs(got - ref) <= 2e-5 * max(1.0, abs(ref)), (got, ref)
+    l2 = losses.L2_regularization([np.ones((2, 2), np.float32), 2 * np.ones(3, np.float32)], 0.5)
+    assert abs(l2 - 0.5 / 2 * (4 / 2 + 12 / 2)) < 1e-12
+
+
+def test_inference_path_labels_embedding_and_png(enet_c3k19, tmp_path):
+    from semanticsegmentationactivelearning_amd import inference as inf
+    from PIL import Image
+    net, P = enet_c3k19
+    x = frames([30, 31], 64, 64, 3)
+    want_logits = orc.enet_forward(P, x)
+    pred = inf.predict_labels(net, dev(x))
+    report_diff("trainId map (bit-exact argmax)", pred.cpu().numpy(), want_logits.argmax(-1).astype(np.uint8))
+    emb = np.zeros(256, np.uint8); emb[:19] = [7, 8, 11, 12, 13, 17, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 31, 32, 33]
+    ids = inf.reverse_embedding(pred, emb).cpu().numpy()
+    assert (ids == emb[want_logits.argmax(-1)]).all()
+    # resized logits (reference inference.py:96-99): compare where the decision margin is not razor thin
+    up = inf.resize_bilinear(dev(want_logits), (96, 80)).cpu().numpy()
+    pred_up = inf.predict_labels(net, dev(x), size=(96, 80)).cpu().numpy()
+    srt = np.sort(up, -1)
+    sure = (srt[..., -1] - srt[..., -2]) > 1e-4
+    assert (pred_up[sure] == up.argmax(-1)[sure]).all() and sure.mean() > 0.99
+    paths = inf.run_inference(net, [(x, [b"a", "b"])], str(tmp_path / "out"), embedding_reversed=emb)
+    assert [os.path.basename(p) for p in paths] == ["a.png", "b.png"]
+    assert (np.asarray(Image.open(paths[1])) == ids[1]).all()

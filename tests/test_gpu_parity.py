@@ -522,3 +522,14 @@ def test_inference_path_labels_embedding_and_png(enet_c3k19, tmp_path):
     paths = inf.run_inference(net, [(x, [b"a", "b"])], str(tmp_path / "out"), embedding_reversed=emb)
     assert [os.path.basename(p) for p in paths] == ["a.png", "b.png"]
     assert (np.asarray(Image.open(paths[1])) == ids[1]).all()
+
+
+def test_forward_c5_medium_rgb_nir(enet_c4k6):
+    """BASELINE config C5 shape family at 256x512: 4-channel input (RGB+NIR), 6 classes, entropy"""
+    net, P = enet_c4k6
+    x = frames([40, 41], 256, 512, 4)
+    got, want = _check_forward(net, P, x, "C5-256x512")
+    want_mean, _, want_label = orc.score_logits(want, "entropy")
+    scores, extra = net.score(dev(x), "entropy", return_label=True)
+    report_diff("C5 label", extra["label"].cpu().numpy(), want_label)
+    report_diff("C5 mean", scores.cpu().numpy(), want_mean, exact=False, atol=1e-6)

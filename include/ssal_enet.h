@@ -157,6 +157,22 @@ int ssal_debug_probe(float *out_dev_256, void *stream);
  * independent accumulators per wave; out_dev needs blocks*256 floats.  Time it with ssal_profile_*. */
 int ssal_debug_mfma_peak(int shape, int blocks, int iters, float *out_dev, void *stream);
 
+/* tuning / A-B knob of the fused bottleneck launchers ("bnk_design", "bnk_wgs", "bnk_split", "bnk_tw",
+ * "bnk_delay", "ablate"; defaults come from the SSAL_* environment).  Every setting of design / wgs /
+ * split / tw produces bit-identical results (tests/test_gpu_parity.py); SSAL_EINVAL for an unknown name. */
+int ssal_debug_set_knob(const char *name, int value);
+
+/* measurement aid (tools/mem_probe.py): y = x for an [n,h,w,64] tensor with the access shape `mode`
+ * (0 linear, 1 MFMA-fragment tile, 2 coalesced tile, 3/4 = 1/2 + halo-ring reads); h % 8 == 0, w % 32 == 0;
+ * spin = shader clocks of ALU work between the loads and the stores. */
+int ssal_debug_copy_probe(int mode, const float *x_dev, float *y_dev, int n, int h, int w, int spin,
+                          void *stream);
+
+/* measurement aid, only functional in a -DSSAL_PHASE_TRACE build (tools/phase_trace.py; SSAL_ENOTIMPL
+ * otherwise): the fused bottleneck kernels write 16 x uint64 per wave (shader-clock phase marks,
+ * 100 MHz realtime of first / last mark, HW_ID, XCC_ID) into buf_dev; NULL switches it off. */
+int ssal_debug_set_trace(void *buf_dev, int64_t bytes);
+
 /* Measurement aid (no reference counterpart): when enabled, every kernel launch is bracketed by
  * HIP events on its own stream; ssal_profile_collect() returns per-kernel launch counts, total
  * milliseconds and ALGORITHMIC flops / bytes as a JSON object.  Single host thread only. */

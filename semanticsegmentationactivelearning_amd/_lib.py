@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libssal_hip.so")
+# SSAL_LIB_PATH: measurement builds only (tools/phase_trace.py loads a -DSSAL_PHASE_TRACE build)
+LIB_PATH = os.environ.get("SSAL_LIB_PATH") or os.path.join(_HERE, "libssal_hip.so")
 
 SSAL_OK, SSAL_EINVAL, SSAL_EHIP, SSAL_ENOTIMPL, SSAL_ESTATE, SSAL_ENOMEM = range(6)
 
@@ -49,6 +50,9 @@ PROTOTYPES = {
     "ssal_set_kernel_family": (_i, [_i]),
     "ssal_debug_probe": (_i, [_vp, _vp]),
     "ssal_debug_mfma_peak": (_i, [_i, _i, _i, _vp, _vp]),
+    "ssal_debug_set_trace": (_i, [_vp, _i64]),
+    "ssal_debug_set_knob": (_i, [ctypes.c_char_p, _i]),
+    "ssal_debug_copy_probe": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ssal_profile_enable": (_i, [_i]),
     "ssal_profile_collect": (_i, [_c.c_char_p, _i64]),
 }
@@ -182,3 +186,8 @@ def profile_collect():
 def set_kernel_family(use_mfma=True):
     """A/B switch: MFMA-fused bottleneck kernels (default) vs the generic kernels; bit-identical."""
     check(lib().ssal_set_kernel_family(1 if use_mfma else 0))
+
+
+def set_knob(name, value):
+    """tuning / A-B knob of the fused bottleneck launchers (include/ssal_enet.h: ssal_debug_set_knob)"""
+    check(lib().ssal_debug_set_knob(name.encode(), int(value)))

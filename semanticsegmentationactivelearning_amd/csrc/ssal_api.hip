@@ -1079,6 +1079,40 @@ SSAL_API int ssal_debug_mfma_peak(int shape, int blocks, int iters, float *out_d
     return SSAL_OK;
 }
 
+SSAL_API int ssal_debug_set_knob(const char *name, int value)
+{
+    if (!name) return fail(SSAL_EINVAL, "NULL knob name");
+    ssal::Knobs &k = ssal::knobs();
+    const std::string n(name);
+    if (n == "bnk_design") k.bnk_design = value;
+    else if (n == "bnk_wgs") k.bnk_wgs = value;
+    else if (n == "bnk_split") k.bnk_split = value;
+    else if (n == "bnk_tw") k.bnk_tw = value;
+    else if (n == "bnk_delay") k.bnk_delay = value;
+    else if (n == "ablate") k.ablate = value;
+    else return fail(SSAL_EINVAL, "unknown knob");
+    return SSAL_OK;
+}
+
+SSAL_API int ssal_debug_copy_probe(int mode, const float *x_dev, float *y_dev, int n, int h, int w, int spin,
+                                   void *stream)
+{
+    if (!x_dev || !y_dev || n <= 0 || h <= 0 || w <= 0) return fail(SSAL_EINVAL, "bad arguments");
+    HIP_TRY(launch_copy_probe(mode, x_dev, y_dev, n, h, w, spin, (hipStream_t)stream));
+    return SSAL_OK;
+}
+
+SSAL_API int ssal_debug_set_trace(void *buf_dev, int64_t bytes)
+{
+    ssal::g_trace_buf = (unsigned long long *)buf_dev;
+    ssal::g_trace_bytes = buf_dev ? (long)bytes : 0;
+#ifdef SSAL_PHASE_TRACE
+    return SSAL_OK;
+#else
+    return buf_dev ? fail(SSAL_ENOTIMPL, "this build has no phase trace (compile with -DSSAL_PHASE_TRACE)") : SSAL_OK;
+#endif
+}
+
 SSAL_API int ssal_profile_enable(int on)
 {
     ssal::g_prof_on = on != 0;

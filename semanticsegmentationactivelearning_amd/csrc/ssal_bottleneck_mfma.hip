@@ -42,15 +42,22 @@ constexpr int PMAX = 352;     // >= (TH+2)*(TW+2) rounded up to a multiple of 32
 template <int TW, int HALO, typename Args>
 __device__ __forceinline__ void proj_to_lds(const Args &a, const float *ximg, float *P, int TH,
                                             int ty0, int tx0, int py, int px, int Hp, int Wp,
-                                            int wave, int j, int h)
-{
+                                            int wave, int j, int h, int prows = PMAX)
+{   // prows = rows P has room for (the last M-tile may reach beyond the halo'd tile)
     constexpr int HWP = TW + 2 * HALO;
     const int d = a.dil;
     const int npix_halo = (TH + 2 * HALO) * HWP;
     // B operand (Wp[ci][co]) for all 64 k-pair steps stays in registers for this wave's M-tiles
-    float wpr[64];
+    // (rows 2s, 2s+1 of Wp are 64 consecutive floats: fragment s of lane l = Wp[64 s + l]).
+    // The first KEEP k-pair steps stay in registers; the tail is re-fetched (L1) per M-tile into the
+    // registers the first activation fragments have just vacated -- this keeps the kernel at 168 VGPRs
+    // = 3 workgroups per CU.
+    constexpr int KEEP = 40, UK = KEEP / 4;  // UK = float4 fragments covered by the resident part
+    float wpr[KEEP];
+    const rsrc_t wrs = make_rsrc(a.wp, C * F * 4);
+    const unsigned wlo = (unsigned)(h * 32 + j) * 4u;
 #pragma unroll
-    for (int s = 0; s < 64; ++s) wpr[s] = a.wp[(2 * s + h) * F + j];
+    for (int s = 0; s < KEEP; ++s) wpr[s] = bload(wrs, wlo, s * 256);
     const float bs = a.ps[j], bt = a.pt[j], ba = a.pa[j];
 
     const int nmt = (npix_halo + 31) / 32;
@@ -64,7 +71,7 @@ __device__ __forceinline__ void proj_to_lds(const Args &a, const float *ximg, fl
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int qi = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                P[qi * PSTR + j] = 0.0f;
+                if (qi < prows) P[qi * PSTR + j] = 0.0f;
             }
             continue;
         }
@@ -77,49 +84,69 @@ __device__ __forceinline__ void proj_to_lds(const Args &a, const float *ximg, fl
             X[u] = *reinterpret_cast<const float4 *>(xp + (2 * u + h) * 4);
         __builtin_amdgcn_sched_barrier(0);
         f32x16 acc = {0};
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {  // float4 u of half h = channels 8u + 4h .. 8u + 4h + 3
+        auto step = [&](int u, float w0, float w1, float w2, float w3) {
             float a0 = X[u].x, a1 = X[u].y, a2 = X[u].z, a3 = X[u].w;
             swap32(a0, a1);  // a0 = ch(8u+0 | 8u+1), a1 = ch(8u+4 | 8u+5)
             swap32(a2, a3);  // a2 = ch(8u+2 | 8u+3), a3 = ch(8u+6 | 8u+7)
-            acc = mfma32(a0, wpr[4 * u + 0], acc);
-            acc = mfma32(a2, wpr[4 * u + 1], acc);
-            acc = mfma32(a1, wpr[4 * u + 2], acc);
-            acc = mfma32(a3, wpr[4 * u + 3], acc);
-        }
+            acc = mfma32(a0, w0, acc);
+            acc = mfma32(a2, w1, acc);
+            acc = mfma32(a1, w2, acc);
+            acc = mfma32(a3, w3, acc);
+        };
+        constexpr int U1 = (64 - KEEP) / 4;  // fragments whose registers the tail weights take over
+#pragma unroll
+        for (int u = 0; u < U1; ++u)  // float4 u of half h = channels 8u + 4h .. 8u + 4h + 3
+            step(u, wpr[4 * u], wpr[4 * u + 1], wpr[4 * u + 2], wpr[4 * u + 3]);
+        __builtin_amdgcn_sched_barrier(0);
+        float wt[64 - KEEP];
+#pragma unroll
+        for (int s = KEEP; s < 64; ++s) wt[s - KEEP] = bload(wrs, wlo, s * 256);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = U1; u < UK; ++u)
+            step(u, wpr[4 * u], wpr[4 * u + 1], wpr[4 * u + 2], wpr[4 * u + 3]);
+#pragma unroll
+        for (int u = UK; u < 16; ++u)
+            step(u, wt[4 * (u - UK)], wt[4 * (u - UK) + 1], wt[4 * (u - UK) + 2], wt[4 * (u - UK) + 3]);
         // epilogue: rows = pixels (registers), cols = co (lanes): BN + PReLU, zero padding
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int ri = (i & 3) + 8 * (i >> 2) + 4 * h;
             const bool ok = (vmask >> ri) & 1ull;
             const float v = ok ? prelu1(fmaf(acc[i], bs, bt), ba) : 0.0f;
-            P[(mt * 32 + ri) * PSTR + j] = v;
+            if (mt * 32 + ri < prows) P[(mt * 32 + ri) * PSTR + j] = v;
         }
     }
 }
 
 // ---- asymmetric only: R1 = conv (5,1) of P, no BN / activation (enet_modules.py:553-558), for the
 // TH x (TW+4) pixels the (1,5) conv needs; D[pixel][co] = P[pixel + kh][ci] * W0[kh][ci][co] -> LDS.
+// R rows = RH consecutive tile rows starting at tile row r0; the last M-tile may run past RH*HWP pixels:
+// its surplus rows read LDS beyond the rows they need (inside the allocation) and are never used.
 template <int TW>
-__device__ __forceinline__ void conv5x1_to_lds(const BnkArgs &a, const float *P, float *R, int TH,
+__device__ __forceinline__ void conv5x1_to_lds(const BnkArgs &a, const float *P, float *R, int r0, int RH,
                                                int wave, int j, int h)
 {
     constexpr int HWP = TW + 4;
-    const int nmt = (TH * HWP) / 32;  // TH = 8: 9 (TW 32) or 5 (TW 16) whole M-tiles
+    const int nmt = (RH * HWP + 31) / 32;  // RH = 4: 5 (TW 32) or 3 (TW 16) M-tiles
+    const rsrc_t wrs = make_rsrc(a.wc, 5 * F * F * 4);
+    const unsigned lo = (unsigned)(h * 32 + j) * 4u;
     for (int mt = wave; mt < nmt; mt += 4) {
         const int u = mt * 32 + j;
         f32x16 acc = {0};
 #pragma unroll 1
         for (int kh = 0; kh < 5; ++kh) {
-            const float *pq = P + (u + kh * HWP) * PSTR + 2 * h;  // pixel (r + kh, c') = u + kh*HWP
-            const float *wt = a.wc + (long)(kh * F + h) * F + j;
+            const float *pq = P + (u + (r0 + kh) * HWP) * PSTR + 2 * h;  // pixel (r0 + r + kh, c')
+            float w[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) w[k] = bload(wrs, lo, kh * (F * F * 4) + k * 256);  // W0[kh][2k + h][j]
 #pragma unroll
             for (int sq = 0; sq < 8; ++sq) {
                 float2 pv = *reinterpret_cast<const float2 *>(pq + 4 * sq);
                 float a0 = pv.x, a1 = pv.y;
                 swap32(a0, a1);  // a0 = ci(4sq | 4sq+1), a1 = ci(4sq+2 | 4sq+3)
-                acc = mfma32(a0, wt[(4 * sq) * F], acc);
-                acc = mfma32(a1, wt[(4 * sq + 2) * F], acc);
+                acc = mfma32(a0, w[2 * sq], acc);
+                acc = mfma32(a1, w[2 * sq + 1], acc);
             }
         }
 #pragma unroll
@@ -147,11 +174,13 @@ __device__ __forceinline__ void conv_tile_q(const Args &a, const float *S, const
     constexpr int NTAP = KH * KW;  // 9 or 5: odd
     float wA[16], wB[16];
     float2 pA[8], pB[8];
+    const rsrc_t wrs = make_rsrc(wconv, NTAP * F * F * 4);
+    const unsigned lo = (unsigned)(h * 32 + j) * 4u;
     auto load_tap = [&](int tap, float (&w)[16], float2 (&p)[8]) {
         const int kh = tap / KW, kw = tap - KW * kh;
-        const float *wt = wconv + (long)(tap * F + h) * F + j;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) w[k] = wt[(2 * k) * F];  // W[tap][ci = 2k + h][co = j]
+        for (int k = 0; k < 16; ++k)  // W[tap][ci = 2k + h][co = j]: rows 2k, 2k+1 = 64 consecutive floats
+            w[k] = bload(wrs, lo, tap * (F * F * 4) + k * 256);
         const float *pq = S + ((r + kh) * SW + (c + kw)) * PSTR + 2 * h;
 #pragma unroll
         for (int sq = 0; sq < 8; ++sq) p[sq] = *reinterpret_cast<const float2 *>(pq + 4 * sq);
@@ -178,11 +207,18 @@ __device__ __forceinline__ void conv_tile_q(const Args &a, const float *S, const
         __builtin_amdgcn_sched_barrier(0);
     }
     run_tap(wA, pA);  // the last (odd) tap
-    // conv epilogue: rows = co (registers), cols = pixel (lanes)
+    // conv epilogue: rows = co (registers), cols = pixel (lanes); co = 8g + 4h + (0..3) per group g
+    {
+        const rsrc_t srs = make_rsrc(a.cs, F * 4), trs = make_rsrc(a.ct, F * 4), ars = make_rsrc(a.ca, F * 4);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int co = (i & 3) + 8 * (i >> 2) + 4 * h;
-        qv[i] = prelu1(fmaf(acc[i], a.cs[co], a.ct[co]), a.ca[co]);
+        for (int g = 0; g < 4; ++g) {
+            const float4 s4 = bload4(srs, h * 16, g * 32), t4 = bload4(trs, h * 16, g * 32),
+                         a4 = bload4(ars, h * 16, g * 32);
+            qv[4 * g + 0] = prelu1(fmaf(acc[4 * g + 0], s4.x, t4.x), a4.x);
+            qv[4 * g + 1] = prelu1(fmaf(acc[4 * g + 1], s4.y, t4.y), a4.y);
+            qv[4 * g + 2] = prelu1(fmaf(acc[4 * g + 2], s4.z, t4.z), a4.z);
+            qv[4 * g + 3] = prelu1(fmaf(acc[4 * g + 3], s4.w, t4.w), a4.w);
+        }
     }
     // the accumulator tile becomes the A operand of the expansion GEMM (lane = pixel)
 #pragma unroll
@@ -195,19 +231,24 @@ template <int TW, int KH, int KW, int SW>
 __device__ __forceinline__ void conv_exp_store(const BnkArgs &a, const float *ximg, float *yimg,
                                                const float *S, const float *wconv, int TH, int ty0,
                                                int tx0, int py, int px, int Hp, int Wp, int wave,
-                                               int j, int h)
+                                               int j, int h, PhaseTrace &tr)
 {
     const int d = a.dil;
     const int nmt_out = (TH * TW) / 32;
+    int trk = 3;
     // raw buffer resources over image n of x and y (num_records = image bytes <= 2 GiB); kOOB is an
     // offset the range check always rejects, even after the +384 B N-tile immediates
     constexpr unsigned kOOB = 0x80000000u;
     const unsigned img_bytes = (unsigned)(a.H * a.W * C) * 4u;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ximg), 0, img_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yimg, 0, img_bytes, 0x00020000);
+    const rsrc_t wers = make_rsrc(a.we, F * C * 4), esrs = make_rsrc(a.es, C * 4), etrs = make_rsrc(a.et, C * 4),
+                 rars = make_rsrc(a.ra, C * 4);
+    const unsigned welo = (unsigned)(h * C + j) * 4u;
     for (int mt = wave; mt < nmt_out; mt += 4) {
         float qv[16];
         conv_tile_q<TW, KH, KW, SW>(a, S, wconv, mt, j, h, qv);
+        tr.mark(trk++);  // 3, 5: conv of this wave's 1st / 2nd M-tile done
 
         // BYTE offsets (inside image n) of the 16 output rows this lane-half stores, lane channel folded
         // in.  Residual loads and output stores go through raw buffer instructions (uniform resource +
@@ -230,16 +271,14 @@ __device__ __forceinline__ void conv_exp_store(const BnkArgs &a, const float *xi
         float weA[16], weB[16], rxA[16], rxB[16];
         float sA, tA, aA, sB, tB, aB;
         auto fetch = [&](int nt, float (&we)[16], float (&rx)[16], float &s1, float &t1, float &al) {
-            const int co = nt * 32 + j;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) we[k] = a.we[(2 * k + h) * C + co];
+            for (int k = 0; k < 16; ++k) we[k] = bload(wers, welo, k * (2 * C * 4) + nt * 128);  // We[2k + h][nt*32 + j]
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                rx[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, boff[i] + nt * 128, 0, 0));
-            s1 = a.es[co]; t1 = a.et[co]; al = a.ra[co];
+            for (int i = 0; i < 16; ++i) rx[i] = bload(xrs, boff[i], nt * 128);
+            s1 = bload(esrs, j * 4, nt * 128); t1 = bload(etrs, j * 4, nt * 128); al = bload(rars, j * 4, nt * 128);
         };
         auto put = [&](int nt, int i, float v) {
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, boff[i] + nt * 128, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, boff[i], nt * 128, 0);
         };
         __builtin_amdgcn_sched_barrier(0);
         fetch(0, weA, rxA, sA, tA, aA);
@@ -274,11 +313,12 @@ __device__ __forceinline__ void conv_exp_store(const BnkArgs &a, const float *xi
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 16; ++s) put(3, s, prelu1(fmaf(e1[s], sB, tB) + rxB[s], aB));
+        tr.mark(trk++);  // 4, 6: expansion + stores issued
     }
 }
 
 struct TileId {
-    int n, py, px, ty0, tx0, Hp, Wp;
+    int n, py, px, ty0, tx0, Hp, Wp, TH;
     bool empty;
 };
 
@@ -288,6 +328,18 @@ __device__ __forceinline__ TileId decode_tile(const BnkArgs &a)
     TileId t;
     const int d = a.dil;
     int b = blockIdx.x;
+    // Anti-phase scheduling (see launch_bottleneck_mfma): the workgroups that fill the SECOND slot of every
+    // CU in the first dispatch round get half-height tiles, so from then on the two co-resident workgroups
+    // of a CU run half a tile apart -- one streams its input while the other one is on the matrix cores.
+    t.TH = a.TH;
+    int row0 = 0;
+    if (b >= a.ntiles) {  // bottom half of a split tile
+        b = a.split_lo + (b - a.ntiles);
+        t.TH = a.TH / 2;
+        row0 = a.TH / 2;
+    } else if (b >= a.split_lo && b < a.split_hi) {  // top half
+        t.TH = a.TH / 2;
+    }
     const int tx = b % a.tiles_x; b /= a.tiles_x;
     const int ty = b % a.tiles_y; b /= a.tiles_y;
     t.px = b % d; b /= d;
@@ -295,50 +347,273 @@ __device__ __forceinline__ TileId decode_tile(const BnkArgs &a)
     t.n = b;
     t.Hp = (a.H - t.py + d - 1) / d;  // rows / cols of this phase sub-image
     t.Wp = (a.W - t.px + d - 1) / d;
-    t.ty0 = ty * a.TH;
+    t.ty0 = ty * a.TH + row0;
     t.tx0 = tx * TW;
     t.empty = (t.ty0 >= t.Hp) || (t.tx0 >= t.Wp);
     return t;
 }
 
-// regular / dilated 3x3 bottleneck
-template <int TW>
-__global__ __launch_bounds__(256, 2) void k_bottleneck_mfma(BnkArgs a)
+// regular / dilated 3x3 bottleneck.  WGS = workgroups per CU the register budget is held to: 3 (168
+// VGPRs, 3 x 47 KB of LDS) is the shipping configuration; 2 is kept for A/B runs (SSAL_BNK_WGS=2).
+template <int TW, int WGS>
+__global__ __launch_bounds__(256, WGS) void k_bottleneck_mfma(BnkArgs a)
 {
     __shared__ float P[PMAX * PSTR];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const TileId t = decode_tile<TW>(a);
     if (t.empty) return;  // whole workgroup: no barrier has been reached yet
+    if (a.delay > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {  // anti-phase experiment
+        const long t0 = __builtin_amdgcn_s_memtime();
+        while ((long)__builtin_amdgcn_s_memtime() - t0 < a.delay) __builtin_amdgcn_s_sleep(16);
+    }
+    PhaseTrace tr;
+    tr.mark(0);
     const float *ximg = a.x + (long)t.n * a.H * a.W * C;
     float *yimg = a.y + (long)t.n * a.H * a.W * C;
     if (a.ablate != 2)
-        proj_to_lds<TW, 1>(a, ximg, P, a.TH, t.ty0, t.tx0, t.py, t.px, t.Hp, t.Wp, wave, j, h);
+        proj_to_lds<TW, 1>(a, ximg, P, t.TH, t.ty0, t.tx0, t.py, t.px, t.Hp, t.Wp, wave, j, h);
+    tr.mark(1);
     __syncthreads();
+    tr.mark(2);
     if (a.ablate == 1) return;
-    conv_exp_store<TW, 3, 3, TW + 2>(a, ximg, yimg, P, a.wc, a.TH, t.ty0, t.tx0, t.py, t.px, t.Hp,
-                                     t.Wp, wave, j, h);
+    conv_exp_store<TW, 3, 3, TW + 2>(a, ximg, yimg, P, a.wc, t.TH, t.ty0, t.tx0, t.py, t.px, t.Hp,
+                                     t.Wp, wave, j, h, tr);
+#ifdef SSAL_PHASE_TRACE
+    __builtin_amdgcn_s_waitcnt(0);  // mark 7 = all stores acknowledged
+#endif
+    tr.mark(7);
+    tr.flush(a.trace, lane, wave);
 }
 
-// asymmetric bottleneck: (5,1) then (1,5) with no BN / activation in between (dilation 1)
-constexpr int PMAX_ASYM = 448;  // >= (8+4)*(32+4) = 432, multiple of 32
+// ---- regular / dilated 3x3 bottleneck, second design: the block input is read ONCE -----------------
+// k_bottleneck_mfma re-reads the residual in its expansion epilogue; at batch 8 the per-XCD working set
+// (11 MB) does not fit the 4 MB L2, so that re-read goes to the fabric (426 MB moved per launch against
+// 268 MB algorithmic) and the kernel sits at the memory roof of this access pattern.  Here the tile's
+// CENTRE pixels are projected with the (wave, M-tile, lane) mapping phase B uses and the expansion is
+// evaluated as D[co][pixel] (lane = pixel): the float4 activation fragments phase A loads (channels
+// 8u + 4h .. +3 of the lane's pixel) are then exactly the residual of output registers 4g .. 4g+3 of
+// N-tile nt = u / 4, g = u % 4 -- they stay in registers (2 x 64 per lane), the one-pixel halo ring is
+// projected separately, and the output leaves as one float4 per lane and register group.
+// The expansion kernel and its BN / PReLU vectors live in LDS: phase B issues no global load after its
+// first store, so stores never sit in front of a load in the in-order vmcnt queue.
 template <int TW>
-__global__ __launch_bounds__(256, 1) void k_bottleneck_mfma_asym(BnkArgs a)
+__global__ __launch_bounds__(256, 2) void k_bottleneck_mfma_r(BnkArgs a)
 {
-    __shared__ float P[PMAX_ASYM * PSTR];
-    __shared__ float R[8 * (TW + 4) * PSTR];
+    constexpr int TH = 8, HWP = TW + 2;
+    constexpr int MPW = (TH * TW) / 32 / 4;  // centre M-tiles per wave: 2 (TW 32) or 1 (TW 16)
+    constexpr int RING = 2 * HWP + 2 * TH;   // halo ring pixels: 84 or 52
+    constexpr int NRMT = (RING + 31) / 32;   // ring M-tiles (3 or 2): wave w < NRMT projects ring tile w
+    constexpr unsigned kOOB = 0x80000000u;   // byte offset the buffer range check always rejects
+    __shared__ float P[PMAX * PSTR];
+    __shared__ float WE[F * C];              // expansion kernel [ci][co]
+    __shared__ float BNV[3 * C];             // es | et | ra
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const TileId t = decode_tile<TW>(a);
+    if (t.empty) return;  // whole workgroup: no barrier has been reached yet
+    PhaseTrace tr;
+    tr.mark(0);
+    const int d = a.dil;
+    const float *ximg = a.x + (long)t.n * a.H * a.W * C;
+    float *yimg = a.y + (long)t.n * a.H * a.W * C;
+    const unsigned img_bytes = (unsigned)(a.H * a.W * C) * 4u;
+    const rsrc_t xrs = make_rsrc(ximg, img_bytes), yrs = make_rsrc(yimg, img_bytes);
+    auto pix_off = [&](int pr, int pc) {  // byte offset of phase-space pixel (pr, pc) in image n, + this half's 16 B
+        return (unsigned)(((t.py + pr * d) * a.W + (t.px + pc * d)) * C + 4 * h) * 4u;
+    };
+
+    // ---- stage the expansion operands in LDS (visible after the barrier) ---------------------------
+    for (int i = threadIdx.x; i < F * C / 4; i += 256)
+        reinterpret_cast<float4 *>(WE)[i] = reinterpret_cast<const float4 *>(a.we)[i];
+    if (threadIdx.x < 3 * C / 4) {
+        const int arr = threadIdx.x / (C / 4), k4 = threadIdx.x % (C / 4);
+        const float *src = arr == 0 ? a.es : arr == 1 ? a.et : a.ra;
+        reinterpret_cast<float4 *>(BNV)[threadIdx.x] = reinterpret_cast<const float4 *>(src)[k4];
+    }
+
+    // ---- phase A ------------------------------------------------------------------------------------
+    // Every activation fragment of the wave (ring tile + MPW centre tiles: 3 x 64 registers) is requested
+    // up front -- ONE exposed HBM latency per workgroup; the projection kernel is streamed from L1 through
+    // a rolling window of WIN k-pair steps instead of living in registers (rows 2s, 2s+1 of Wp = 64
+    // consecutive floats: fragment s of lane l = Wp[64 s + l]).
+    constexpr int WIN = 8;
+    const rsrc_t wrs = make_rsrc(a.wp, C * F * 4);
+    const unsigned wlo = (unsigned)lane * 4u;
+    const float bs = a.ps[j], bt = a.pt[j], ba = a.pa[j];
+
+    auto load_frags = [&](unsigned off, float4 (&X)[16]) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) X[u] = bload4(xrs, off, u * 32);  // channels 8u + 4h .. +3
+    };
+    // project the 32 pixels of one M-tile (vmask: in-image pixels; qf(ri): P row of M-tile pixel ri)
+    auto project = [&](const float4 (&X)[16], unsigned vmask, auto qf) {
+        f32x16 acc = {0};
+        float wa[WIN], wb[WIN];
+        auto fetch_w = [&](int s0, float (&w)[WIN]) {
+#pragma unroll
+            for (int s = 0; s < WIN; ++s) w[s] = bload(wrs, wlo, (s0 + s) * 256);
+        };
+        auto steps = [&](int s0, const float (&w)[WIN]) {  // WIN k-pair steps = WIN / 4 activation fragments
+#pragma unroll
+            for (int v = 0; v < WIN / 4; ++v) {
+                const int u = s0 / 4 + v;
+                float a0 = X[u].x, a1 = X[u].y, a2 = X[u].z, a3 = X[u].w;
+                swap32(a0, a1);  // a0 = ch(8u+0 | 8u+1), a1 = ch(8u+4 | 8u+5)
+                swap32(a2, a3);  // a2 = ch(8u+2 | 8u+3), a3 = ch(8u+6 | 8u+7)
+                acc = mfma32(a0, w[4 * v + 0], acc);
+                acc = mfma32(a2, w[4 * v + 1], acc);
+                acc = mfma32(a1, w[4 * v + 2], acc);
+                acc = mfma32(a3, w[4 * v + 3], acc);
+            }
+        };
+        fetch_w(0, wa);
+#pragma unroll
+        for (int s0 = 0; s0 < 64; s0 += 2 * WIN) {
+            fetch_w(s0 + WIN, wb);
+            __builtin_amdgcn_sched_barrier(0);
+            steps(s0, wa);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s0 + 2 * WIN < 64) fetch_w(s0 + 2 * WIN, wa);
+            __builtin_amdgcn_sched_barrier(0);
+            steps(s0 + WIN, wb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {  // rows = pixels (registers), cols = co (lanes)
+            const int ri = (i & 3) + 8 * (i >> 2) + 4 * h;
+            const int q = qf(ri);
+            const bool ok = (vmask >> ri) & 1u;
+            const float v = ok ? prelu1(fmaf(acc[i], bs, bt), ba) : 0.0f;  // exact zero outside the image
+            P[q * PSTR + j] = v;
+        }
+    };
+    constexpr int QDUMP = PMAX - 1;  // spare P row: where M-tile pixels beyond the ring are written
+    auto q_ring = [&](int u) {       // halo'd-tile index of ring pixel u (branch-free)
+        const int k = u - 2 * HWP;
+        const int side = (1 + (k >> 1)) * HWP + ((k & 1) ? HWP - 1 : 0);
+        const int q = u < HWP ? u : (u < 2 * HWP ? (TH + 1) * HWP + (u - HWP) : side);
+        return u < RING ? q : QDUMP;
+    };
+
+    float4 xk[MPW][16];  // centre activation fragments == residual of phase B
+    unsigned offk[MPW];  // byte offset of the lane's pixel (+ 16 h), kOOB outside the image
+#pragma unroll
+    for (int k = 0; k < MPW; ++k) {
+        const int tt = (wave + 4 * k) * 32 + j;
+        const int pr = t.ty0 + tt / TW, pc = t.tx0 + tt % TW;
+        offk[k] = (pr < t.Hp && pc < t.Wp) ? pix_off(pr, pc) : kOOB;
+    }
+    {
+        // ring tile of this wave (waves >= NRMT have none: their offsets are out of range, the loads
+        // return zeros without touching memory) and the first centre tile, requested together
+        float4 XR[16];
+        const int u = wave * 32 + j;
+        const int q = q_ring(u);
+        const int pr = t.ty0 - 1 + q / HWP, pc = t.tx0 - 1 + q % HWP;
+        const bool rvalid = (wave < NRMT) && (u < RING) && pr >= 0 && pr < t.Hp && pc >= 0 && pc < t.Wp;
+        load_frags(rvalid ? pix_off(pr, pc) : kOOB, XR);
+#pragma unroll
+        for (int k = 0; k < MPW; ++k) load_frags(offk[k], xk[k]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (wave < NRMT) {  // wave-uniform
+            const unsigned vmask = (unsigned)__ballot(rvalid);
+            project(XR, vmask, [&](int ri) { return q_ring(wave * 32 + ri); });
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < MPW; ++k) {
+        const int mt = wave + 4 * k;
+        const unsigned vmask = (unsigned)__ballot(offk[k] != kOOB);
+        project(xk[k], vmask, [&](int ri) { const int tt = mt * 32 + ri; return (tt / TW + 1) * HWP + (tt % TW) + 1; });
+    }
+    tr.mark(1);
+    __syncthreads();
+    tr.mark(2);
+
+    // ---- phase B: conv -> expansion D[co][pixel] -> + residual (registers) -> float4 stores ----------
+    const float *wel = WE + h * C + j;          // We[2s + h][nt*32 + j] = wel[2s*C + nt*32]
+    const float *bnl = BNV + 4 * h;             // vectors of channels nt*32 + 8g + 4h .. +3
+#pragma unroll
+    for (int k = 0; k < MPW; ++k) {
+        const int mt = wave + 4 * k;
+        float qv[16];
+        conv_tile_q<TW, 3, 3, HWP>(a, P, a.wc, mt, j, h, qv);
+        tr.mark(3 + 2 * k);
+        auto chain = [&](int nt, int s, f32x16 e) { return mfma32(wel[2 * s * C + nt * 32], qv[ord(s)], e); };
+        auto epilogue = [&](int nt, int g, const f32x16 &e) {
+            const float4 s4 = *reinterpret_cast<const float4 *>(bnl + nt * 32 + 8 * g);
+            const float4 t4 = *reinterpret_cast<const float4 *>(bnl + C + nt * 32 + 8 * g);
+            const float4 a4 = *reinterpret_cast<const float4 *>(bnl + 2 * C + nt * 32 + 8 * g);
+            const float4 x4 = xk[k][4 * nt + g];
+            float4 o;
+            o.x = prelu1(fmaf(e[4 * g + 0], s4.x, t4.x) + x4.x, a4.x);
+            o.y = prelu1(fmaf(e[4 * g + 1], s4.y, t4.y) + x4.y, a4.y);
+            o.z = prelu1(fmaf(e[4 * g + 2], s4.z, t4.z) + x4.z, a4.z);
+            o.w = prelu1(fmaf(e[4 * g + 3], s4.w, t4.w) + x4.w, a4.w);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yrs, offk[k], nt * 128 + g * 32, 0);
+        };
+        // the MFMA chain of N-tile nt+1 is issued interleaved with the epilogue of N-tile nt
+        f32x16 e0 = {0}, e1 = {0};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) e0 = chain(0, s, e0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int s = 4 * g; s < 4 * g + 4; ++s) e1 = chain(1, s, e1);
+            epilogue(0, g, e0);
+        }
+        e0 = (f32x16){0};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int s = 4 * g; s < 4 * g + 4; ++s) e0 = chain(2, s, e0);
+            epilogue(1, g, e1);
+        }
+        e1 = (f32x16){0};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int s = 4 * g; s < 4 * g + 4; ++s) e1 = chain(3, s, e1);
+            epilogue(2, g, e0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) epilogue(3, g, e1);
+        tr.mark(4 + 2 * k);
+    }
+#ifdef SSAL_PHASE_TRACE
+    __builtin_amdgcn_s_waitcnt(0);  // mark 7 = all stores acknowledged
+#endif
+    tr.mark(7);
+    tr.flush(a.trace, lane, wave);
+}
+
+// asymmetric bottleneck: (5,1) then (1,5) with no BN / activation in between (dilation 1).
+// LDS: P = the projected tile with a 2-pixel halo (12 x 36 pixels), R = the (5,1) result for FOUR tile
+// rows at a time (4 x 36 pixels, + the tail of the last M-tile): the tile is finished in two halves, which
+// keeps the workgroup at 80.5 KB of LDS = two workgroups per CU (all 8 rows at once: 100 KB = one).
+constexpr int PROWS_ASYM = 432;  // (8+4)*(32+4)
+constexpr int RROWS_ASYM = 160;  // 5 M-tiles of 32 >= 4*(32+4)
+template <int TW>
+__global__ __launch_bounds__(256, 2) void k_bottleneck_mfma_asym(BnkArgs a)
+{
+    __shared__ float P[PROWS_ASYM * PSTR];
+    __shared__ float R[RROWS_ASYM * PSTR];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const TileId t = decode_tile<TW>(a);
     if (t.empty) return;
     const float *ximg = a.x + (long)t.n * a.H * a.W * C;
     float *yimg = a.y + (long)t.n * a.H * a.W * C;
-    proj_to_lds<TW, 2>(a, ximg, P, a.TH, t.ty0, t.tx0, t.py, t.px, t.Hp, t.Wp, wave, j, h);
-    __syncthreads();
-    conv5x1_to_lds<TW>(a, P, R, a.TH, wave, j, h);
-    __syncthreads();
-    conv_exp_store<TW, 1, 5, TW + 4>(a, ximg, yimg, R, a.wc2, a.TH, t.ty0, t.tx0, t.py, t.px, t.Hp,
-                                     t.Wp, wave, j, h);
+    proj_to_lds<TW, 2>(a, ximg, P, t.TH, t.ty0, t.tx0, t.py, t.px, t.Hp, t.Wp, wave, j, h, PROWS_ASYM);
+    PhaseTrace tr;
+    for (int r0 = 0; r0 < t.TH; r0 += 4) {
+        __syncthreads();  // P complete (first half) / R free again (second half)
+        conv5x1_to_lds<TW>(a, P, R, r0, 4, wave, j, h);
+        __syncthreads();
+        conv_exp_store<TW, 1, 5, TW + 4>(a, ximg, yimg, R, a.wc2, 4, t.ty0 + r0, t.tx0, t.py, t.px, t.Hp,
+                                         t.Wp, wave, j, h, tr);
+    }
 }
 
 // =================================================================================================
@@ -706,6 +981,37 @@ hipError_t launch_mfma_peak(int shape, int blocks, int iters, float *out, hipStr
     return hipGetLastError();
 }
 
+static int num_cus()
+{
+    static int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+        return v;
+    }();
+    return n;
+}
+
+Knobs &knobs()
+{
+    static Knobs k = [] {
+        auto env = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
+        Knobs q;
+        q.bnk_design = env("SSAL_BNK_DESIGN", 1);
+        q.bnk_wgs = env("SSAL_BNK_WGS", 3);
+        q.bnk_split = env("SSAL_BNK_SPLIT", 0);
+        q.bnk_tw = env("SSAL_BNK_TW", 0);
+        q.bnk_delay = env("SSAL_BNK_DELAY", 0);
+        q.ablate = env("SSAL_ABLATE", 0);
+        return q;
+    }();
+    return k;
+}
+
+unsigned long long *g_trace_buf = nullptr;
+long g_trace_bytes = 0;
+
 hipError_t launch_probe_swap(float *out, hipStream_t s)
 {
     hipLaunchKernelGGL(k_probe_swap, dim3(1), dim3(64), 0, s, out);
@@ -813,19 +1119,31 @@ hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W,
     a.wc = wc; a.wc2 = wc2; a.cs = cs; a.ct = ct; a.ca = ca;
     a.we = we; a.es = es; a.et = et; a.ra = ra;
     a.N = N; a.H = H; a.W = W; a.dil = dil;
-    {
-        static const int ablate = getenv("SSAL_ABLATE") ? atoi(getenv("SSAL_ABLATE")) : 0;
-        a.ablate = ablate;
-    }
+    const Knobs &kn = knobs();
+    a.ablate = kn.ablate;
+    a.delay = kn.bnk_delay;
+    a.trace = nullptr;
     if (Cin != C) return launch_bottleneck_mfma16(a, Cin, s);
     a.TH = 8;
     const int Hp = (H + dil - 1) / dil, Wp = (W + dil - 1) / dil;  // largest phase sub-image
-    const bool wide = Wp > 16;
+    const bool wide = Wp > 16 && kn.bnk_tw != 16;
     const int TW = wide ? 32 : 16;
     a.tiles_y = (Hp + a.TH - 1) / a.TH;
     a.tiles_x = (Wp + TW - 1) / TW;
     const long grid = (long)N * dil * dil * a.tiles_y * a.tiles_x;
     if (grid <= 0 || grid > 0x7fffffffL) return hipErrorInvalidValue;
+    a.ntiles = (int)grid;
+    a.split_lo = a.split_hi = 0;
+    long launch_grid = grid;
+    const int design = kn.bnk_design;
+    const bool split_on = !asym && design == 1 && kn.bnk_split && grid >= 2L * num_cus();
+    const int wgs = split_on ? 2 : kn.bnk_wgs;  // anti-phase scheduling assumes exactly two workgroups per CU
+    if (split_on) {
+        a.split_lo = num_cus();
+        a.split_hi = 2 * num_cus();
+        launch_grid = grid + num_cus();
+    }
+    if (g_trace_buf && launch_grid * 4 * 16 * 8 <= g_trace_bytes) a.trace = g_trace_buf;
     const double pix = (double)N * H * W;
     const double f = Cin / 4.0;
     const double taps = asym ? 10.0 : 9.0;
@@ -838,10 +1156,19 @@ hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W,
         else
             hipLaunchKernelGGL(k_bottleneck_mfma_asym<16>, dim3((unsigned)grid), dim3(256), 0, s, a);
     } else {
-        if (wide)
-            hipLaunchKernelGGL(k_bottleneck_mfma<32>, dim3((unsigned)grid), dim3(256), 0, s, a);
+        const dim3 G((unsigned)launch_grid), B(256);
+        if (design == 2 && wide)
+            hipLaunchKernelGGL(k_bottleneck_mfma_r<32>, G, B, 0, s, a);
+        else if (design == 2)
+            hipLaunchKernelGGL(k_bottleneck_mfma_r<16>, G, B, 0, s, a);
+        else if (wide && wgs == 2)
+            hipLaunchKernelGGL((k_bottleneck_mfma<32, 2>), G, B, 0, s, a);
+        else if (wide)
+            hipLaunchKernelGGL((k_bottleneck_mfma<32, 3>), G, B, 0, s, a);
+        else if (wgs == 2)
+            hipLaunchKernelGGL((k_bottleneck_mfma<16, 2>), G, B, 0, s, a);
         else
-            hipLaunchKernelGGL(k_bottleneck_mfma<16>, dim3((unsigned)grid), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((k_bottleneck_mfma<16, 3>), G, B, 0, s, a);
     }
     return hipGetLastError();
 }

@@ -168,6 +168,8 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck16(BnkArgs a)
     if (ty0 >= Hp || tx0 >= Wp) return;
     const float *ximg = a.x + (long)n * a.H * a.W * CC;
     float *yimg = a.y + (long)n * a.H * a.W * CC;
+    PhaseTrace tr;
+    tr.mark(0);
 
     // ---- phase A: projection of centre + ring into LDS -------------------------------------------
     const bool cval = i16 < FF;
@@ -222,6 +224,24 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck16(BnkArgs a)
 #pragma unroll
         for (int m = 0; m < NT; ++m) xk[k][m] = *reinterpret_cast<const float4 *>(xp + 16 * m);
     }
+    // the halo-ring fragments are requested in the same breath (ONE exposed HBM latency per workgroup,
+    // not two): this wave's ring M-tiles are wave, wave + 4 (RM = 2 for the 84-pixel ring of a 32-wide tile)
+    constexpr int RM = (RING + 63) / 64;
+    float4 xr[RM][NT];
+    bool rvalid[RM];
+#pragma unroll
+    for (int k = 0; k < RM; ++k) {
+        const int u = (wave + 4 * k) * 16 + i16;
+        const int q = u < RING ? q_ring(u) : 0;
+        const int hr = q / HW2, hc = q - hr * HW2;
+        const int pr = ty0 - 1 + hr, pc = tx0 - 1 + hc;
+        rvalid[k] = (u < RING) && (pr >= 0) && (pr < Hp) && (pc >= 0) && (pc < Wp);
+        const float *xp = rvalid[k] ? ximg + ((long)(py + pr * d) * a.W + (px + pc * d)) * CC + 4 * g : ximg + 4 * g;
+#pragma unroll
+        for (int m = 0; m < NT; ++m) xr[k][m] = *reinterpret_cast<const float4 *>(xp + 16 * m);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
 #pragma unroll
     for (int k = 0; k < MPW; ++k) {
         const int mt = wave + 4 * k;
@@ -231,27 +251,24 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck16(BnkArgs a)
         for (int r = 0; r < 4; ++r) qrow[r] = q_center(mt * 16 + 4 * g + r);
         if (a.ablate != 2) project(xk[k], vmask, qrow);
     }
-    for (int mtr = wave; mtr * 16 < RING; mtr += 4) {  // halo ring
-        const int u = mtr * 16 + i16;
-        const int q = u < RING ? q_ring(u) : 0;
-        const int hr = q / HW2, hc = q - hr * HW2;
-        const int pr = ty0 - 1 + hr, pc = tx0 - 1 + hc;
-        const bool valid = (u < RING) && (pr >= 0) && (pr < Hp) && (pc >= 0) && (pc < Wp);
-        const unsigned vmask = (unsigned)(__ballot(valid) & 0xFFFFull);
-        int qrow[4];
+    tr.mark(1);  // centre projected (activation loads have arrived)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ur = mtr * 16 + 4 * g + r;
-            qrow[r] = ur < RING ? q_ring(ur) : -1;
+    for (int k = 0; k < RM; ++k) {  // halo ring
+        const int mtr = wave + 4 * k;
+        if (mtr * 16 < RING) {  // wave-uniform
+            const unsigned vmask = (unsigned)(__ballot(rvalid[k]) & 0xFFFFull);
+            int qrow[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ur = mtr * 16 + 4 * g + r;
+                qrow[r] = ur < RING ? q_ring(ur) : -1;
+            }
+            if (a.ablate != 2) project(xr[k], vmask, qrow);
         }
-        float4 v[NT];
-        const float *xp = valid ? ximg + ((long)(py + pr * d) * a.W + (px + pc * d)) * CC + 4 * g : ximg + 4 * g;
-#pragma unroll
-        for (int m = 0; m < NT; ++m) v[m] = *reinterpret_cast<const float4 *>(xp + 16 * m);
-        if (a.ablate != 2) project(v, vmask, qrow);
     }
 
-    // loop-invariant operands of phase B, requested before the barrier so their latency overlaps it
+    // every loop-invariant operand of phase B is requested before the barrier: nothing in phase B waits
+    // on a global load, so its stores never sit in front of a load in the (in-order) vmcnt queue.
     float wcr[9 * KF];
     load_conv16_weights<FF>(a, i16, g, wcr);
     float cs[4], ct[4], ca[4];
@@ -261,8 +278,17 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck16(BnkArgs a)
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int s = 0; s < KF; ++s) wer[nt * KF + s] = a.we[(4 * s + g) * CC + nt * 16 + i16];
+    float4 es4[NT], et4[NT], ra4[NT];  // expansion BN / residual PReLU of channels nt*16 + 4g .. +3
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        es4[nt] = *reinterpret_cast<const float4 *>(a.es + nt * 16 + 4 * g);
+        et4[nt] = *reinterpret_cast<const float4 *>(a.et + nt * 16 + 4 * g);
+        ra4[nt] = *reinterpret_cast<const float4 *>(a.ra + nt * 16 + 4 * g);
+    }
 
+    tr.mark(2);  // ring projected, phase-B operands requested
     __syncthreads();
+    tr.mark(3);
     if (a.ablate == 1) return;
 
     // ---- phase B: conv, expansion, residual (from registers), store -------------------------------
@@ -271,15 +297,13 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck16(BnkArgs a)
         const int mt = wave + 4 * k;
         float q[4];
         conv16_tile_q<TW, FF>(P, wcr, cs, ct, ca, mt, i16, g, q);
+        if (k == 0) tr.mark(4);  // first conv done
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             f32x4 e = {0};
 #pragma unroll
             for (int s = 0; s < KF; ++s) e = mfma16(wer[nt * KF + s], q[s], e);
-            const int co = nt * 16 + 4 * g;  // reg r = channel co + r
-            const float4 s1 = *reinterpret_cast<const float4 *>(a.es + co);
-            const float4 t1 = *reinterpret_cast<const float4 *>(a.et + co);
-            const float4 al = *reinterpret_cast<const float4 *>(a.ra + co);
+            const float4 s1 = es4[nt], t1 = et4[nt], al = ra4[nt];  // reg r = channel nt*16 + 4g + r
             float4 o;
             o.x = prelu1(fmaf(e[0], s1.x, t1.x) + xk[k][nt].x, al.x);
             o.y = prelu1(fmaf(e[1], s1.y, t1.y) + xk[k][nt].y, al.y);
@@ -287,7 +311,14 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck16(BnkArgs a)
             o.w = prelu1(fmaf(e[3], s1.w, t1.w) + xk[k][nt].w, al.w);
             if (offk[k] >= 0) *reinterpret_cast<float4 *>(yimg + offk[k] + nt * 16) = o;
         }
+        if (k == 0) tr.mark(5);  // first M-tile stored (issued)
     }
+    tr.mark(6);
+#ifdef SSAL_PHASE_TRACE
+    __builtin_amdgcn_s_waitcnt(0);  // mark 7 = all stores acknowledged
+#endif
+    tr.mark(7);
+    tr.flush(a.trace, lane, wave);
 }
 
 // =================================================================================================
@@ -560,6 +591,7 @@ hipError_t launch_bottleneck_mfma16(const BnkArgs &a0, int Cin, hipStream_t s)
     a.tiles_x = (Wp + TW - 1) / TW;
     const long grid = (long)a.N * a.dil * a.dil * a.tiles_y * a.tiles_x;
     if (grid <= 0 || grid > 0x7fffffffL) return hipErrorInvalidValue;
+    a.trace = (g_trace_buf && grid * 4 * 16 * 8 <= g_trace_bytes) ? g_trace_buf : nullptr;
     const double pix = (double)a.N * a.H * a.W, f = Cin / 4.0;
     ProfScope prof(Cin == 64 ? "k_bottleneck16<64,16>" : "k_bottleneck16<16,4>",
                    2.0 * pix * (Cin * f + 9.0 * f * f + f * Cin), 4.0 * 2.0 * pix * Cin, s);

@@ -97,7 +97,24 @@ hipError_t launch_upsample_mfma(const float *x, float *y, const uint8_t *code, i
                                 const float *ws, const float *cs, const float *ct, const float *ca,
                                 const float *we, const float *es, const float *et, const float *wr,
                                 const float *ra, hipStream_t s);
+// Tuning / measurement knobs of the fused bottleneck launchers (defaults = the shipping configuration;
+// initialised from the SSAL_* environment once, changed at run time with ssal_debug_set_knob for A/B runs
+// and for the tests that compare the variants bit for bit).
+struct Knobs {
+    int bnk_design;  // 1 = residual re-read in the expansion epilogue, 2 = residual kept in registers
+    int bnk_wgs;     // design 1: workgroups per CU the register budget is held to (2 or 3)
+    int bnk_split;   // design 1: anti-phase half tiles for the second dispatch slot of every CU
+    int bnk_tw;      // 16 = force 8x16 tiles
+    int bnk_delay;   // shader clocks workgroups 256..511 spin before starting (experiment)
+    int ablate;      // 1 = stop after the projection phase, 2 = skip it (timing only, results invalid)
+};
+Knobs &knobs();
+
+// phase-trace buffer the bottleneck launchers hand to their kernels (ssal_debug_set_trace; NULL = off)
+extern unsigned long long *g_trace_buf;
+extern long g_trace_bytes;
 hipError_t launch_probe_swap(float *out, hipStream_t s);
+hipError_t launch_copy_probe(int mode, const float *x, float *y, int N, int H, int W, int spin, hipStream_t s);
 hipError_t launch_mfma_peak(int shape, int blocks, int iters, float *out, hipStream_t s);
 
 hipError_t launch_prelu(const float *x, int64_t pixels, int C, const float *alpha, float *y,

@@ -57,6 +57,57 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c)
 
 __device__ __forceinline__ float prelu1(float v, float a) { return v >= 0.0f ? v : a * v; }
 
+// Raw buffer access (uniform 128-bit resource in SGPRs + 32-bit lane offset + uniform offset): no
+// per-lane 64-bit address registers, and the hardware range check (offset >= bytes) returns 0 / drops
+// the store.  Weight fragments are addressed as  lane part (VGPR) + step part (SGPR / immediate).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
+
+__device__ __forceinline__ float bload(rsrc_t r, unsigned voff, unsigned soff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
+__device__ __forceinline__ float4 bload4(rsrc_t r, unsigned voff, unsigned soff)
+{
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+// Phase timestamps of one wave (measurement aid; compiled in only with -DSSAL_PHASE_TRACE, see
+// tools/phase_trace.py): marks are s_memtime shader-clock reads kept in SGPRs, flushed by lane 0 at the
+// end of the kernel: 16 x u64 per wave = t[0..11], realtime(100 MHz) first / last mark, HW_ID, XCC_ID.
+struct PhaseTrace {
+#ifdef SSAL_PHASE_TRACE
+    unsigned long long t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long r0 = 0, r1 = 0;
+#endif
+    __device__ __forceinline__ void mark(int k)
+    {
+#ifdef SSAL_PHASE_TRACE
+        t[k] = __builtin_amdgcn_s_memtime();
+        if (k == 0) r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    }
+    __device__ __forceinline__ void flush(unsigned long long *buf, int lane, int wave)
+    {
+#ifdef SSAL_PHASE_TRACE
+        r1 = __builtin_amdgcn_s_memrealtime();
+        if (buf && lane == 0) {
+            unsigned long long *p = buf + ((long)blockIdx.x * 4 + wave) * 16;
+            for (int k = 0; k < 12; ++k) p[k] = t[k];
+            p[12] = r0; p[13] = r1;
+            p[14] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+            p[15] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+        }
+#endif
+    }
+};
+
 // 32x32x2 family: register order in which pair-swapped accumulator registers deliver ascending
 // channel pairs: 0,2,1,3, 4,6,5,7, ...  (swap bits 0 and 1 of the step index)
 __device__ __host__ constexpr int ord(int s) { return (s & ~3) | ((s & 1) << 1) | ((s >> 1) & 1); }

@@ -1,0 +1,108 @@
+// ssal_probe.hip -- memory-pattern probes (measurement aid, tools/mem_probe.py): y = x for an NHWC
+// tensor with 64 channels, using the access shapes the fused kernels use, to find out what the memory
+// system sustains for each shape.  No product path calls these.
+#include "ssal_internal.h"
+#include "ssal_prof.h"
+
+namespace ssal {
+
+// mode 0: linear, one float4 per thread
+__global__ __launch_bounds__(256) void k_probe_linear(const float4 *x, float4 *y, long n4)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) y[i] = x[i];
+}
+
+// modes 1..: one workgroup per 8 x 32 pixel tile (C = 64: 256 B per pixel), 4 waves, each wave 4 groups
+// of 16 consecutive pixels (the M-tiles of k_bottleneck16).
+//   FRAG = true : lane (i16, g) moves bytes [64 m + 16 g, +16) of pixel i16, m = 0..3  (MFMA operand shape)
+//   FRAG = false: lane l moves bytes [1024 m + 16 l, +16) of the 4 KB group              (fully coalesced)
+//   HALO        : additionally reads the one-pixel ring of the tile (as phase A does), result discarded
+//   SPIN        : shader-clock cycles of dependent ALU work between the loads and the stores
+template <bool FRAG, bool HALO, int TH = 8, int TW = 32>
+__global__ __launch_bounds__(256) void k_probe_tile(const float *x, float *y, int H, int W, int spin)
+{
+    constexpr int C = 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int tiles_x = W / TW, tiles_y = H / TH;
+    int b = blockIdx.x;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y; b /= tiles_y;
+    const float *ximg = x + (long)b * H * W * C;
+    float *yimg = y + (long)b * H * W * C;
+    float4 v[4][4];
+    long off[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int t0 = (wave + 4 * k) * 16;  // first pixel of the group inside the tile
+        const int r = t0 / TW, c = t0 % TW;
+        const long base = ((long)(ty * TH + r) * W + tx * TW + c) * C;
+        off[k] = FRAG ? base + (long)i16 * C + 4 * g : base + 4 * lane;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            v[k][m] = *reinterpret_cast<const float4 *>(ximg + off[k] + (FRAG ? 16 * m : 256 * m));
+    }
+    float4 hv[2][4];
+    if (HALO) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int u = (wave + 4 * k) * 16 + i16;  // ring pixel 0..83
+            int hr, hc;
+            if (u < 34) { hr = -1; hc = u - 1; }
+            else if (u < 68) { hr = TH; hc = u - 35; }
+            else { const int q = u - 68; hr = q >> 1; hc = (q & 1) ? TW : -1; }
+            const int py = ty * TH + hr, px = tx * TW + hc;
+            const bool ok = u < 84 && py >= 0 && py < H && px >= 0 && px < W;
+            const float *p = ximg + (ok ? ((long)py * W + px) * C : 0) + 4 * g;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) hv[k][m] = *reinterpret_cast<const float4 *>(p + 16 * m);
+        }
+    }
+    if (spin > 0) {
+        float acc = v[0][0].x;
+        const long t0 = __builtin_amdgcn_s_memtime();
+        while ((long)__builtin_amdgcn_s_memtime() - t0 < spin) acc = fmaf(acc, 1.0000001f, 1e-9f);
+        if (acc == 12345.678f) v[0][0].x = acc;
+    }
+    if (HALO) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) s += hv[k][m].x + hv[k][m].w;
+        if (s == 12345.678f) v[0][0].y = s;  // keeps the ring loads alive
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            *reinterpret_cast<float4 *>(yimg + off[k] + (FRAG ? 16 * m : 256 * m)) = v[k][m];
+}
+
+hipError_t launch_copy_probe(int mode, const float *x, float *y, int N, int H, int W, int spin, hipStream_t s)
+{
+    if (H % 16 || W % 256) return hipErrorInvalidValue;
+    const long n = (long)N * H * W * 64;
+    static const char *names[] = {"probe linear", "probe tile frag", "probe tile coalesced", "probe tile frag+halo",
+                                  "probe tile coalesced+halo"};
+    if (mode < 0 || mode > 8) return hipErrorInvalidValue;
+    ProfScope prof(mode <= 4 ? names[mode] : "probe tile shape", 0.0, 8.0 * n, s);
+    const unsigned tiles = (unsigned)((long)N * (H / 8) * (W / 32));
+    switch (mode) {
+    case 0: hipLaunchKernelGGL(k_probe_linear, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s,
+                               (const float4 *)x, (float4 *)y, n / 4); break;
+    case 1: hipLaunchKernelGGL((k_probe_tile<true, false>), dim3(tiles), dim3(256), 0, s, x, y, H, W, spin); break;
+    case 2: hipLaunchKernelGGL((k_probe_tile<false, false>), dim3(tiles), dim3(256), 0, s, x, y, H, W, spin); break;
+    case 3: hipLaunchKernelGGL((k_probe_tile<true, true>), dim3(tiles), dim3(256), 0, s, x, y, H, W, spin); break;
+    case 4: hipLaunchKernelGGL((k_probe_tile<false, true>), dim3(tiles), dim3(256), 0, s, x, y, H, W, spin); break;
+    // fragment-shaped accesses, other tile shapes with the same 256 pixels per workgroup
+    case 5: hipLaunchKernelGGL((k_probe_tile<true, false, 4, 64>), dim3(tiles), dim3(256), 0, s, x, y, H, W, spin); break;
+    case 6: hipLaunchKernelGGL((k_probe_tile<true, false, 2, 128>), dim3(tiles), dim3(256), 0, s, x, y, H, W, spin); break;
+    case 7: hipLaunchKernelGGL((k_probe_tile<true, false, 1, 256>), dim3(tiles), dim3(256), 0, s, x, y, H, W, spin); break;
+    case 8: hipLaunchKernelGGL((k_probe_tile<true, false, 16, 16>), dim3(tiles), dim3(256), 0, s, x, y, H, W, spin); break;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace ssal

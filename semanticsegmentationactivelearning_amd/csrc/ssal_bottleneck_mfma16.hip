@@ -146,16 +146,22 @@ __device__ __forceinline__ void load_conv16_bn(const Args &a, int g, float (&cs)
 // stay in registers across the barrier; the one-pixel halo ring is projected separately.
 // =================================================================================================
 template <int TW, int CC, int FF>
-__global__ __launch_bounds__(256, 2) void k_bottleneck16(BnkArgs a)
+__global__ __launch_bounds__(256, 3) void k_bottleneck16(BnkArgs a)
 {
     constexpr int PS = FF + 2, KF = FF / 4, NT = CC / 16, HW2 = TW + 2, KP = CC / 4;
     constexpr int TH = 8;                      // tile rows (launcher guarantees a.TH == 8)
     constexpr int MPW = (TH * TW) / 16 / 4;    // centre M-tiles per wave: 4 (TW 32) or 2 (TW 16)
     constexpr int RING = 2 * HW2 + 2 * TH;     // halo ring pixels: 84 or 52
     __shared__ float P[PMAX16 * PS];
+    __shared__ float BNV[3 * CC];  // es | et | ra: read in phase B through LDS (no global load after a store)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, g = lane >> 4;
     const int d = a.dil;
+    if (threadIdx.x < 3 * CC / 4) {
+        const int arr = threadIdx.x / (CC / 4), k4 = threadIdx.x % (CC / 4);
+        const float *src = arr == 0 ? a.es : arr == 1 ? a.et : a.ra;
+        reinterpret_cast<float4 *>(BNV)[threadIdx.x] = reinterpret_cast<const float4 *>(src)[k4];
+    }
     int b = blockIdx.x;
     const int tx = b % a.tiles_x; b /= a.tiles_x;
     const int ty = b % a.tiles_y; b /= a.tiles_y;
@@ -278,13 +284,6 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck16(BnkArgs a)
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int s = 0; s < KF; ++s) wer[nt * KF + s] = a.we[(4 * s + g) * CC + nt * 16 + i16];
-    float4 es4[NT], et4[NT], ra4[NT];  // expansion BN / residual PReLU of channels nt*16 + 4g .. +3
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        es4[nt] = *reinterpret_cast<const float4 *>(a.es + nt * 16 + 4 * g);
-        et4[nt] = *reinterpret_cast<const float4 *>(a.et + nt * 16 + 4 * g);
-        ra4[nt] = *reinterpret_cast<const float4 *>(a.ra + nt * 16 + 4 * g);
-    }
 
     tr.mark(2);  // ring projected, phase-B operands requested
     __syncthreads();
@@ -303,7 +302,10 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck16(BnkArgs a)
             f32x4 e = {0};
 #pragma unroll
             for (int s = 0; s < KF; ++s) e = mfma16(wer[nt * KF + s], q[s], e);
-            const float4 s1 = es4[nt], t1 = et4[nt], al = ra4[nt];  // reg r = channel nt*16 + 4g + r
+            // expansion BN / residual PReLU of channels nt*16 + 4g .. +3 (reg r = channel nt*16 + 4g + r)
+            const float4 s1 = *reinterpret_cast<const float4 *>(BNV + nt * 16 + 4 * g);
+            const float4 t1 = *reinterpret_cast<const float4 *>(BNV + CC + nt * 16 + 4 * g);
+            const float4 al = *reinterpret_cast<const float4 *>(BNV + 2 * CC + nt * 16 + 4 * g);
             float4 o;
             o.x = prelu1(fmaf(e[0], s1.x, t1.x) + xk[k][nt].x, al.x);
             o.y = prelu1(fmaf(e[1], s1.y, t1.y) + xk[k][nt].y, al.y);

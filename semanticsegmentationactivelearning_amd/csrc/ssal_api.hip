@@ -331,6 +331,17 @@ std::vector<float> hwoi_to_hwio(const std::vector<float> &w, int O, int I)
             for (int i = 0; i < I; ++i) r[((size_t)t * I + i) * O + o] = w[((size_t)t * O + o) * I + i];
     return r;
 }
+
+// [rows][K] -> [rows][K2], K2 = K rounded up to even, zero padded: k_final_score reads class PAIRS
+std::vector<float> pad_cols_even(const std::vector<float> &w, int K)
+{
+    const int K2 = (K + 1) / 2 * 2;
+    const size_t rows = w.size() / K;
+    std::vector<float> r(rows * K2, 0.0f);
+    for (size_t i = 0; i < rows; ++i)
+        for (int k = 0; k < K; ++k) r[i * K2 + k] = w[i * K + k];
+    return r;
+}
 }  // namespace
 
 SSAL_API int ssal_enet_commit(ssal_enet *net, void *stream)
@@ -400,7 +411,7 @@ SSAL_API int ssal_enet_commit(ssal_enet *net, void *stream)
             break;
         }
         case K_FINAL:
-            o.v[0] = ab.push(hwoi_to_hwio(T(net, n + "kernel"), net->classes, c));
+            o.v[0] = ab.push(pad_cols_even(hwoi_to_hwio(T(net, n + "kernel"), net->classes, c), net->classes));
             L.f = L.cf = 0;
             break;
         }

@@ -355,18 +355,60 @@ __device__ __forceinline__ double block_sum_256(double v, double *lds4)
 //   out(2i  ,2j+1) = a*W01 + b*W21
 //   out(2i+1,2j  ) = a*W10 + c*W12
 //   out(2i+1,2j+1) = a*W11                      (taps listed in (kh,kw) ascending = oracle order)
-// wF = [3][3][16][K].  grid = (ceil(H*W/256), N): a block never straddles two images.
+// wF = [3][3][16][K2], K2 = K rounded up to even (zero padded at commit): two classes per
+// v_pk_fma_f32 -- the kernel tap pair sits in an aligned SGPR pair, the activation is broadcast to both
+// halves (op_sel), each half is an ordinary IEEE fma, so the chain per class is unchanged.
+// grid = (ceil(H*W/256), N): a block never straddles two images.
 // ------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// One kernel tap (16 input channels x K classes) applied to the class-pair accumulators.  The taps are
+// wave-uniform: they are read with scalar loads and enter v_pk_fma_f32 as SGPR pairs.  The 9 x 16 x K2 of
+// them do not fit the SGPR file, so they stream through two buffers of G input channels each: the scalar
+// loads of group g+1 (or of the first group of the NEXT tap, wnext) are issued before the FMAs of group
+// g; sched_barrier pins that order.  (Left alone the compiler hoists whole taps and spills ~1500 SGPRs
+// through v_writelane / v_readlane, doubling the VALU work of this VALU-bound kernel.)
+// On entry w0 holds group 0 of this tap; on exit it holds group 0 of wnext (if not NULL).
 template <int K>
-__device__ __forceinline__ void tap16(float (&acc)[K], const float (&v)[16],
-                                      const float *__restrict__ wtap)
-{
+struct FsTap {
+    static constexpr int KP = (K + 1) / 2;           // class pairs
+    static constexpr int G = 2 * KP <= 20 ? 2 : 1;   // input channels per group
+    static constexpr int NG = 16 / G, WN = G * 2 * KP, TS = 16 * 2 * KP;
+    static __device__ __forceinline__ void load(const float *__restrict__ p, float (&w)[WN])
+    {
 #pragma unroll
-    for (int ci = 0; ci < 16; ++ci) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) acc[k] = fmaf(v[ci], wtap[ci * K + k], acc[k]);
+        for (int q = 0; q < WN; ++q) w[q] = p[q];
     }
-}
+    static __device__ __forceinline__ void fma(f32x2 (&acc)[KP], const float (&v)[16], int c0, const float (&w)[WN])
+    {
+#pragma unroll
+        for (int c = 0; c < G; ++c) {
+            const f32x2 a2 = {v[c0 + c], v[c0 + c]};
+#pragma unroll
+            for (int p = 0; p < KP; ++p) {
+                const f32x2 w2 = {w[c * 2 * KP + 2 * p], w[c * 2 * KP + 2 * p + 1]};
+                acc[p] = __builtin_elementwise_fma(a2, w2, acc[p]);
+            }
+        }
+    }
+    static __device__ __forceinline__ void apply(f32x2 (&acc)[KP], const float (&v)[16],
+                                                 const float *__restrict__ wtap, const float *__restrict__ wnext,
+                                                 float (&w0)[WN], float (&w1)[WN])
+    {
+#pragma unroll
+        for (int g = 0; g < NG; g += 2) {
+            load(wtap + (g + 1) * WN, w1);
+            __builtin_amdgcn_sched_barrier(0);
+            fma(acc, v, g * G, w0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 2 < NG) load(wtap + (g + 2) * WN, w0);
+            else if (wnext) load(wnext, w0);
+            __builtin_amdgcn_sched_barrier(0);
+            fma(acc, v, (g + 1) * G, w1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+};
 
 template <int K>
 __global__ __launch_bounds__(256) void k_final_score(const float *__restrict__ x, int N, int H,
@@ -406,25 +448,18 @@ __global__ __launch_bounds__(256) void k_final_score(const float *__restrict__ x
         }
         const float inv_logK = 1.0f / __logf((float)K);
         const int Wo = 2 * W;
+        typedef FsTap<K> FT;
+        constexpr int KP = FT::KP, TS = FT::TS;
+        float w0[FT::WN], w1[FT::WN];
+        f32x2 acc2[KP];
 #pragma unroll
-        for (int quad = 0; quad < 4; ++quad) {
+        for (int k = 0; k < KP; ++k) acc2[k] = (f32x2){0.0f, 0.0f};
+        auto finish_quad = [&](int quad) {
             float acc[K];
 #pragma unroll
-            for (int k = 0; k < K; ++k) acc[k] = 0.0f;
-            if (quad == 0) {  // (even, even): taps (0,0) a, (0,2) c, (2,0) b, (2,2) d
-                tap16<K>(acc, va, wF + (0 * 3 + 0) * 16 * K);
-                tap16<K>(acc, vc, wF + (0 * 3 + 2) * 16 * K);
-                tap16<K>(acc, vb, wF + (2 * 3 + 0) * 16 * K);
-                tap16<K>(acc, vd, wF + (2 * 3 + 2) * 16 * K);
-            } else if (quad == 1) {  // (even, odd): (0,1) a, (2,1) b
-                tap16<K>(acc, va, wF + (0 * 3 + 1) * 16 * K);
-                tap16<K>(acc, vb, wF + (2 * 3 + 1) * 16 * K);
-            } else if (quad == 2) {  // (odd, even): (1,0) a, (1,2) c
-                tap16<K>(acc, va, wF + (1 * 3 + 0) * 16 * K);
-                tap16<K>(acc, vc, wF + (1 * 3 + 2) * 16 * K);
-            } else {  // (odd, odd): (1,1) a
-                tap16<K>(acc, va, wF + (1 * 3 + 1) * 16 * K);
-            }
+            for (int k = 0; k < K; ++k) acc[k] = (k & 1) ? acc2[k >> 1].y : acc2[k >> 1].x;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) acc2[k] = (f32x2){0.0f, 0.0f};
             const int oy = 2 * i + (quad >> 1), ox = 2 * j + (quad & 1);
             const long op = ((long)n * 2 * H + oy) * Wo + ox;
             if (logits) {
@@ -438,7 +473,26 @@ __global__ __launch_bounds__(256) void k_final_score(const float *__restrict__ x
             if (label) label[op] = (uint8_t)lab;
             if (mask) mask[op] = cf < threshold ? (uint8_t)0 : (uint8_t)1;
             if (conf) conf[op] = cf;
-        }
+        };
+        auto tap = [&](int kh, int kw) { return wF + (kh * 3 + kw) * TS; };
+        FT::load(tap(0, 0), w0);
+        // (even, even): taps (0,0) a, (0,2) c, (2,0) b, (2,2) d
+        FT::apply(acc2, va, tap(0, 0), tap(0, 2), w0, w1);
+        FT::apply(acc2, vc, tap(0, 2), tap(2, 0), w0, w1);
+        FT::apply(acc2, vb, tap(2, 0), tap(2, 2), w0, w1);
+        FT::apply(acc2, vd, tap(2, 2), tap(0, 1), w0, w1);
+        finish_quad(0);
+        // (even, odd): (0,1) a, (2,1) b
+        FT::apply(acc2, va, tap(0, 1), tap(2, 1), w0, w1);
+        FT::apply(acc2, vb, tap(2, 1), tap(1, 0), w0, w1);
+        finish_quad(1);
+        // (odd, even): (1,0) a, (1,2) c
+        FT::apply(acc2, va, tap(1, 0), tap(1, 2), w0, w1);
+        FT::apply(acc2, vc, tap(1, 2), tap(1, 1), w0, w1);
+        finish_quad(2);
+        // (odd, odd): (1,1) a
+        FT::apply(acc2, va, tap(1, 1), nullptr, w0, w1);
+        finish_quad(3);
     }
     const double r = block_sum_256(local, red);
     if (threadIdx.x == 0) partial[(long)n * gridDim.x + blockIdx.x] = r;

@@ -37,24 +37,23 @@ __device__ __forceinline__ void proj16_to_lds(const Args &a, const float *ximg, 
     }
     const float bs = a.ps[ic], bt = a.pt[ic], ba = a.pa[ic];
     const int nmt = (npix_halo + 15) / 16;
-    for (int mt = wave; mt < nmt; mt += 4) {
+    // the activation fragments of M-tile mt + 4 are requested before M-tile mt is projected
+    auto frags = [&](int mt, float4 (&v)[CC / 16], bool &valid) {
         const int q = mt * 16 + i16;
         const int hr = q / HW2, hc = q - hr * HW2;
         const int pr = ty0 - 1 + hr, pc = tx0 - 1 + hc;
-        const bool valid = (q < npix_halo) && (pr >= 0) && (pr < Hp) && (pc >= 0) && (pc < Wp);
-        const unsigned vmask = (unsigned)(__ballot(valid) & 0xFFFFull);
-        if (vmask == 0u) {
-            if (cval) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) P[(mt * 16 + 4 * g + r) * PS + i16] = 0.0f;
-            }
-            continue;
-        }
+        valid = (q < npix_halo) && (pr >= 0) && (pr < Hp) && (pc >= 0) && (pc < Wp);
         const float *xp = valid ? ximg + ((long)(py + pr * d) * a.W + (px + pc * d)) * CC : ximg;
-        float4 v[CC / 16];
 #pragma unroll
         for (int m = 0; m < CC / 16; ++m)  // quarter g takes the g-th float4 of every 16 channels
             v[m] = *reinterpret_cast<const float4 *>(xp + 16 * m + 4 * g);
+    };
+    float4 v[CC / 16], vn[CC / 16];
+    bool valid = false, validn = false;
+    if (wave < nmt) frags(wave, v, valid);
+    for (int mt = wave; mt < nmt; mt += 4) {
+        if (mt + 4 < nmt) frags(mt + 4, vn, validn);
+        const unsigned vmask = (unsigned)(__ballot(valid) & 0xFFFFull);
         f32x4 acc = {0};
 #pragma unroll
         for (int m = 0; m < CC / 16; ++m) {
@@ -73,6 +72,9 @@ __device__ __forceinline__ void proj16_to_lds(const Args &a, const float *ximg, 
                 P[(mt * 16 + pix) * PS + i16] = ok ? prelu1(fmaf(acc[r], bs, bt), ba) : 0.0f;
             }
         }
+#pragma unroll
+        for (int m = 0; m < CC / 16; ++m) v[m] = vn[m];
+        valid = validn;
     }
 }
 
@@ -331,8 +333,14 @@ __global__ __launch_bounds__(256, 4) void k_downsample16(DownArgs a)
 {
     constexpr int CI = 16, FF = 8, CO = 64, PS = FF + 2, HW2 = TW + 2;
     __shared__ float P[PMAX16 * PS];
+    __shared__ float BNV[3 * CO];  // es | et | ra, read in phase B through LDS
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, g = lane >> 4;
+    if (threadIdx.x < 3 * CO / 4) {
+        const int arr = threadIdx.x / (CO / 4), k4 = threadIdx.x % (CO / 4);
+        const float *src = arr == 0 ? a.es : arr == 1 ? a.et : a.ra;
+        reinterpret_cast<float4 *>(BNV)[threadIdx.x] = reinterpret_cast<const float4 *>(src)[k4];
+    }
     const int Ho = a.H / 2, Wo = a.W / 2;
     int b = blockIdx.x;
     const int tx = b % a.tiles_x; b /= a.tiles_x;
@@ -357,24 +365,23 @@ __global__ __launch_bounds__(256, 4) void k_downsample16(DownArgs a)
         const float bs = a.ps[ic], bt = a.pt[ic], ba = a.pa[ic];
         const int npix_halo = (TH + 2) * HW2;
         const int nmt = (npix_halo + 15) / 16;
-        for (int mt = wave; mt < nmt; mt += 4) {
+        // the 2x2 patch fragments of M-tile mt + 4 are requested before M-tile mt is projected
+        auto patch = [&](int mt, float4 (&v)[4], bool &valid) {
             const int q = mt * 16 + i16;
             const int hr = q / HW2, hc = q - hr * HW2;
             const int pr = ty0 - 1 + hr, pc = tx0 - 1 + hc;
-            const bool valid = (q < npix_halo) && (pr >= 0) && (pr < Ho) && (pc >= 0) && (pc < Wo);
-            const unsigned vmask = (unsigned)(__ballot(valid) & 0xFFFFull);
-            if (vmask == 0u) {
-                if (cval) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) P[(mt * 16 + 4 * g + r) * PS + i16] = 0.0f;
-                }
-                continue;
-            }
+            valid = (q < npix_halo) && (pr >= 0) && (pr < Ho) && (pc >= 0) && (pc < Wo);
             const float *xp = valid ? ximg + ((long)(2 * pr) * a.W + 2 * pc) * CI : ximg;
-            float4 v[4];
 #pragma unroll
             for (int tap = 0; tap < 4; ++tap)
                 v[tap] = *reinterpret_cast<const float4 *>(xp + ((tap >> 1) * a.W + (tap & 1)) * CI + 4 * g);
+        };
+        float4 v[4], vn[4];
+        bool valid = false, validn = false;
+        if (wave < nmt) patch(wave, v, valid);
+        for (int mt = wave; mt < nmt; mt += 4) {
+            if (mt + 4 < nmt) patch(mt + 4, vn, validn);
+            const unsigned vmask = (unsigned)(__ballot(valid) & 0xFFFFull);
             f32x4 acc = {0};
 #pragma unroll
             for (int tap = 0; tap < 4; ++tap) {
@@ -393,6 +400,9 @@ __global__ __launch_bounds__(256, 4) void k_downsample16(DownArgs a)
                     P[(mt * 16 + pix) * PS + i16] = ok ? prelu1(fmaf(acc[r], bs, bt), ba) : 0.0f;
                 }
             }
+#pragma unroll
+            for (int tap = 0; tap < 4; ++tap) v[tap] = vn[tap];
+            valid = validn;
         }
     }
     __syncthreads();
@@ -410,18 +420,27 @@ __global__ __launch_bounds__(256, 4) void k_downsample16(DownArgs a)
         wer[nt * 2 + 1] = a.we[(4 + g) * CO + nt * 16 + i16];
     }
     const int nmt_out = (TH * TW) / 16;
-    for (int mt = wave; mt < nmt_out; mt += 4) {
+    // pooling window of channels 4g..4g+3 (N-tile 0) of M-tile mt; requested one M-tile ahead, i.e. BEFORE
+    // the stores of the current M-tile (loads return in order: a load behind a store waits for its ack)
+    auto window = [&](int mt, float4 (&pv)[4], bool &ok, long &opix) {
         const int t = mt * 16 + i16;
         const int rr = t / TW, cc = t - rr * TW;
         const int oy = ty0 + rr, ox = tx0 + cc;
-        const bool ok = (oy < Ho) && (ox < Wo);
-        const long opix = ok ? (long)oy * Wo + ox : 0;
-        // pooled residual of channels 4g..4g+3 (N-tile 0): 2x2 window, first maximum wins
+        ok = (oy < Ho) && (ox < Wo);
+        opix = ok ? (long)oy * Wo + ox : 0;
         const float *w0 = ximg + (ok ? ((long)(2 * oy) * a.W + 2 * ox) * CI : 0) + 4 * g;
-        const float4 v00 = *reinterpret_cast<const float4 *>(w0);
-        const float4 v01 = *reinterpret_cast<const float4 *>(w0 + CI);
-        const float4 v10 = *reinterpret_cast<const float4 *>(w0 + (long)a.W * CI);
-        const float4 v11 = *reinterpret_cast<const float4 *>(w0 + (long)a.W * CI + CI);
+        pv[0] = *reinterpret_cast<const float4 *>(w0);
+        pv[1] = *reinterpret_cast<const float4 *>(w0 + CI);
+        pv[2] = *reinterpret_cast<const float4 *>(w0 + (long)a.W * CI);
+        pv[3] = *reinterpret_cast<const float4 *>(w0 + (long)a.W * CI + CI);
+    };
+    float4 pv[4], pn[4];
+    bool ok = false, okn = false;
+    long opix = 0, opixn = 0;
+    if (wave < nmt_out) window(wave, pv, ok, opix);
+    for (int mt = wave; mt < nmt_out; mt += 4) {
+        if (mt + 4 < nmt_out) window(mt + 4, pn, okn, opixn);
+        const float4 v00 = pv[0], v01 = pv[1], v10 = pv[2], v11 = pv[3];  // first maximum wins
 
         float q[4];
         conv16_tile_q<TW, FF>(P, wcr, cs, ct, ca, mt, i16, g, q);
@@ -452,9 +471,9 @@ __global__ __launch_bounds__(256, 4) void k_downsample16(DownArgs a)
             e = mfma16(wer[nt * 2 + 0], q[0], e);
             e = mfma16(wer[nt * 2 + 1], q[1], e);
             const int co = nt * 16 + 4 * g;  // reg r = channel co + r
-            const float4 s1 = *reinterpret_cast<const float4 *>(a.es + co);
-            const float4 t1 = *reinterpret_cast<const float4 *>(a.et + co);
-            const float4 al = *reinterpret_cast<const float4 *>(a.ra + co);
+            const float4 s1 = *reinterpret_cast<const float4 *>(BNV + co);
+            const float4 t1 = *reinterpret_cast<const float4 *>(BNV + CO + co);
+            const float4 al = *reinterpret_cast<const float4 *>(BNV + 2 * CO + co);
             const float4 rr4 = nt == 0 ? rx : make_float4(0.f, 0.f, 0.f, 0.f);
             float4 o;
             o.x = prelu1(fmaf(e[0], s1.x, t1.x) + rr4.x, al.x);
@@ -463,6 +482,10 @@ __global__ __launch_bounds__(256, 4) void k_downsample16(DownArgs a)
             o.w = prelu1(fmaf(e[3], s1.w, t1.w) + rr4.w, al.w);
             if (ok) *reinterpret_cast<float4 *>(yimg + opix * CO + co) = o;
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pv[k] = pn[k];
+        ok = okn;
+        opix = opixn;
     }
 }
 
@@ -472,7 +495,7 @@ __global__ __launch_bounds__(256, 4) void k_downsample16(DownArgs a)
 // ssal_bottleneck_mfma.hip), exp 8 -> 16, residual 1x1 conv 64 -> 16 + gather-unpool.
 // =================================================================================================
 template <int TW>
-__global__ __launch_bounds__(256, 4) void k_upsample16(UpArgs a)
+__global__ __launch_bounds__(256, 3) void k_upsample16(UpArgs a)
 {
     constexpr int CI = 64, PF = 16, CF = 8, CO = 16, PS = PF + 2, HW2 = TW + 2;
     __shared__ float P[PMAX16 * PS];
@@ -508,21 +531,41 @@ __global__ __launch_bounds__(256, 4) void k_upsample16(UpArgs a)
 #pragma unroll
     for (int s_ = 0; s_ < 16; ++s_) wrr[s_] = a.wr[(4 * s_ + g) * CO + i16];
 
+    // stacked transposed-conv kernel as A operand, all 6 slots (identical for every M-tile)
+    float wsr[6 * 4];
+#pragma unroll
+    for (int slot = 0; slot < 6; ++slot)
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) wsr[slot * 4 + s_] = a.ws[(slot * PF + 4 * s_ + g) * 16 + i16];
+
     const int nmt = (TH * TW) / 16;
-    for (int mt = wave; mt < nmt; mt += 4) {
+    // activation fragments (residual conv) and window codes of M-tile mt: requested one M-tile ahead, i.e.
+    // BEFORE the stores of the current M-tile (loads return in order: a load behind a store waits for its ack)
+    auto fetch = [&](int mt, float4 (&xv)[4], unsigned &codes, bool &ok, long &ipix) {
         const int t = mt * 16 + i16;
         const int r_ = t / TW, c_ = t - r_ * TW;
         const int iy = ty0 + r_, ix = tx0 + c_;
-        const bool ok = (iy < a.H) && (ix < a.W);
-        const long ipix = ok ? (long)iy * a.W + ix : 0;
+        ok = (iy < a.H) && (ix < a.W);
+        ipix = ok ? (long)iy * a.W + ix : 0;
+        const float *xp = ximg + ipix * CI;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) xv[m] = *reinterpret_cast<const float4 *>(xp + 16 * m + 4 * g);
+        codes = *reinterpret_cast<const unsigned *>(cimg + ipix * CO + 4 * g);
+    };
+    float4 v[4], vn[4];
+    unsigned codes = 0, codesn = 0;
+    bool ok = false, okn = false;
+    long ipix = 0, ipixn = 0;
+    if (wave < nmt) fetch(wave, v, codes, ok, ipix);
+    for (int mt = wave; mt < nmt; mt += 4) {
+        if (mt + 4 < nmt) fetch(mt + 4, vn, codesn, okn, ipixn);
+        const int t = mt * 16 + i16;
+        const int r_ = t / TW, c_ = t - r_ * TW;
+        const int iy = ty0 + r_, ix = tx0 + c_;
 
         // ---- residual branch: D[co][pixel] = Wr^T[co][ci] * X[ci][pixel]  (64 -> 16) -----------------
         f32x4 res = {0};
         {
-            const float *xp = ximg + ipix * CI;
-            float4 v[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) v[m] = *reinterpret_cast<const float4 *>(xp + 16 * m + 4 * g);
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 float r0 = v[m].x, r1 = v[m].y, r2 = v[m].z, r3 = v[m].w;
@@ -533,19 +576,16 @@ __global__ __launch_bounds__(256, 4) void k_upsample16(UpArgs a)
                 res = mfma16(wrr[4 * m + 3], r3, res);
             }
         }
-        const unsigned codes = *reinterpret_cast<const unsigned *>(cimg + ipix * CO + 4 * g);
-
         // ---- transposed conv 16 -> 8: accA rows [ee|eo], accB rows [oe|oo] ---------------------------
         f32x4 accA = {0}, accB = {0};
 #pragma unroll
         for (int slot = 0; slot < 6; ++slot) {
             const int dr = slot < 4 ? 1 - (slot >> 1) : 1, dc = 1 - (slot & 1);
             const float *pq = P + ((r_ + dr) * HW2 + (c_ + dc)) * PS + g;
-            const float *wt = a.ws + (slot * PF + g) * 16 + i16;
 #pragma unroll
             for (int s_ = 0; s_ < 4; ++s_) {
-                if (slot < 4) accA = mfma16(wt[(4 * s_) * 16], pq[4 * s_], accA);
-                else          accB = mfma16(wt[(4 * s_) * 16], pq[4 * s_], accB);
+                if (slot < 4) accA = mfma16(wsr[slot * 4 + s_], pq[4 * s_], accA);
+                else          accB = mfma16(wsr[slot * 4 + s_], pq[4 * s_], accB);
             }
         }
         float qa[4], qb[4];
@@ -573,6 +613,11 @@ __global__ __launch_bounds__(256, 4) void k_upsample16(UpArgs a)
             o.w = prelu1(fmaf(e[3], s1.w, t1.w) + (((codes >> 24) & 0xFFu) == (unsigned)cls ? res[3] : 0.0f), al.w);
             if (ok) *reinterpret_cast<float4 *>(yp + ((cls >> 1) * (2 * a.W) + (cls & 1)) * CO) = o;
         }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) v[m] = vn[m];
+        codes = codesn;
+        ok = okn;
+        ipix = ipixn;
     }
     (void)CF;
 }

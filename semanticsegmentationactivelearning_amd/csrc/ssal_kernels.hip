@@ -372,7 +372,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int K>
 struct FsTap {
     static constexpr int KP = (K + 1) / 2;           // class pairs
-    static constexpr int G = 2 * KP <= 20 ? 2 : 1;   // input channels per group
+    static constexpr int G = 1;  // input channels per group (2 was measured: 80 buffer SGPRs crowd out the
+                                 // kernel's pointers -> ~470 lane moves per thread, 6 % slower)
     static constexpr int NG = 16 / G, WN = G * 2 * KP, TS = 16 * 2 * KP;
     static __device__ __forceinline__ void load(const float *__restrict__ p, float (&w)[WN])
     {

@@ -158,7 +158,7 @@ int ssal_debug_probe(float *out_dev_256, void *stream);
 int ssal_debug_mfma_peak(int shape, int blocks, int iters, float *out_dev, void *stream);
 
 /* tuning / A-B knob of the fused bottleneck launchers ("bnk_design", "bnk_wgs", "bnk_split", "bnk_tw",
- * "bnk_delay", "ablate"; defaults come from the SSAL_* environment).  Every setting of design / wgs /
+ * "ablate"; defaults come from the SSAL_* environment).  Every setting of design / wgs /
  * split / tw produces bit-identical results (tests/test_gpu_parity.py); SSAL_EINVAL for an unknown name. */
 int ssal_debug_set_knob(const char *name, int value);
 

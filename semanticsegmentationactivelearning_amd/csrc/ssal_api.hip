@@ -1099,7 +1099,6 @@ SSAL_API int ssal_debug_set_knob(const char *name, int value)
     else if (n == "bnk_wgs") k.bnk_wgs = value;
     else if (n == "bnk_split") k.bnk_split = value;
     else if (n == "bnk_tw") k.bnk_tw = value;
-    else if (n == "bnk_delay") k.bnk_delay = value;
     else if (n == "ablate") k.ablate = value;
     else return fail(SSAL_EINVAL, "unknown knob");
     return SSAL_OK;

@@ -22,7 +22,6 @@ struct BnkArgs {
     int ntiles;            // N * dil^2 * tiles_y * tiles_x
     int split_lo, split_hi;  // tiles in [split_lo, split_hi) are processed as two 4-row half tiles: workgroup
                              // `tile` takes the top half, workgroup ntiles + (tile - split_lo) the bottom half
-    int delay;             // measurement aid (SSAL_BNK_DELAY env): shader clocks workgroups 256..511 wait before starting
     int ablate;            // measurement aid (SSAL_ABLATE env): 1 = stop after the projection phase,
                            // 2 = skip the projection phase (results invalid; timing only)
 };

@@ -317,6 +317,71 @@ __device__ __forceinline__ void conv_exp_store(const BnkArgs &a, const float *xi
     }
 }
 
+// ---- the same phase with the expansion operands in LDS (WE = We[ci][co], BNV = es | et | ra): the only
+// global loads of the phase are the conv kernel fragments and the residual, and ALL 64 residual values of
+// an M-tile are requested in one go right after the conv (whose kernel fragments are ahead of them in the
+// in-order vmcnt queue), so the epilogues wait for HBM once per M-tile instead of once per N-tile.
+template <int TW, int KH, int KW, int SW>
+__device__ __forceinline__ void conv_exp_store_lds(const BnkArgs &a, const float *ximg, float *yimg,
+                                                   const float *S, const float *wconv, const float *WE,
+                                                   const float *BNV, int TH, int ty0, int tx0, int py, int px,
+                                                   int Hp, int Wp, int wave, int j, int h, PhaseTrace &tr)
+{
+    const int d = a.dil;
+    const int nmt_out = (TH * TW) / 32;
+    int trk = 3;
+    constexpr unsigned kOOB = 0x80000000u;
+    const unsigned img_bytes = (unsigned)(a.H * a.W * C) * 4u;
+    const rsrc_t xrs = make_rsrc(ximg, img_bytes), yrs = make_rsrc(yimg, img_bytes);
+    const float *wel = WE + h * C + j;  // We[2s + h][nt*32 + j] = wel[2s*C + nt*32]
+    for (int mt = wave; mt < nmt_out; mt += 4) {
+        float qv[16];
+        conv_tile_q<TW, KH, KW, SW>(a, S, wconv, mt, j, h, qv);
+        tr.mark(trk++);
+        unsigned boff[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ti = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const int rr = ti / TW, cc = ti - rr * TW;
+            const int pr = ty0 + rr, pc = tx0 + cc;
+            const bool ok = (pr < Hp) && (pc < Wp);
+            boff[i] = ok ? (unsigned)((((py + pr * d) * a.W + (px + pc * d)) * C + j) * 4) : kOOB;
+        }
+        float rx[4][16];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) rx[nt][i] = bload(xrs, boff[i], nt * 128);
+        __builtin_amdgcn_sched_barrier(0);
+        auto chain = [&](int nt, int s0, f32x16 e) {
+#pragma unroll
+            for (int s = s0; s < s0 + 4; ++s) e = mfma32(qv[ord(s)], wel[2 * s * C + nt * 32], e);
+            return e;
+        };
+        auto epi = [&](int nt, int i0, const f32x16 &e) {
+            const float s1 = BNV[nt * 32 + j], t1 = BNV[C + nt * 32 + j], al = BNV[2 * C + nt * 32 + j];
+#pragma unroll
+            for (int i = i0; i < i0 + 4; ++i)
+                __builtin_amdgcn_raw_buffer_store_b32(
+                    __builtin_bit_cast(unsigned, prelu1(fmaf(e[i], s1, t1) + rx[nt][i], al)), yrs, boff[i], nt * 128, 0);
+        };
+        f32x16 e0 = {0}, e1 = {0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e0 = chain(0, 4 * q, e0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { e1 = chain(1, 4 * q, e1); epi(0, 4 * q, e0); }
+        e0 = (f32x16){0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { e0 = chain(2, 4 * q, e0); epi(1, 4 * q, e1); }
+        e1 = (f32x16){0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { e1 = chain(3, 4 * q, e1); epi(2, 4 * q, e0); }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) epi(3, 4 * q, e1);
+        tr.mark(trk++);
+    }
+}
+
 struct TileId {
     int n, py, px, ty0, tx0, Hp, Wp, TH;
     bool empty;
@@ -359,26 +424,38 @@ template <int TW, int WGS>
 __global__ __launch_bounds__(256, WGS) void k_bottleneck_mfma(BnkArgs a)
 {
     __shared__ float P[PMAX * PSTR];
+    constexpr bool LDSW = WGS == 2;  // two workgroups per CU leave LDS room for the expansion operands
+    __shared__ float WE[LDSW ? F * C : 1];
+    __shared__ float BNV[LDSW ? 3 * C : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const TileId t = decode_tile<TW>(a);
     if (t.empty) return;  // whole workgroup: no barrier has been reached yet
-    if (a.delay > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {  // anti-phase experiment
-        const long t0 = __builtin_amdgcn_s_memtime();
-        while ((long)__builtin_amdgcn_s_memtime() - t0 < a.delay) __builtin_amdgcn_s_sleep(16);
-    }
     PhaseTrace tr;
     tr.mark(0);
     const float *ximg = a.x + (long)t.n * a.H * a.W * C;
     float *yimg = a.y + (long)t.n * a.H * a.W * C;
+    if (LDSW) {
+        for (int i = threadIdx.x; i < F * C / 4; i += 256)
+            reinterpret_cast<float4 *>(WE)[i] = reinterpret_cast<const float4 *>(a.we)[i];
+        if (threadIdx.x < 3 * C / 4) {
+            const int arr = threadIdx.x / (C / 4), k4 = threadIdx.x % (C / 4);
+            const float *src = arr == 0 ? a.es : arr == 1 ? a.et : a.ra;
+            reinterpret_cast<float4 *>(BNV)[threadIdx.x] = reinterpret_cast<const float4 *>(src)[k4];
+        }
+    }
     if (a.ablate != 2)
         proj_to_lds<TW, 1>(a, ximg, P, t.TH, t.ty0, t.tx0, t.py, t.px, t.Hp, t.Wp, wave, j, h);
     tr.mark(1);
     __syncthreads();
     tr.mark(2);
     if (a.ablate == 1) return;
-    conv_exp_store<TW, 3, 3, TW + 2>(a, ximg, yimg, P, a.wc, t.TH, t.ty0, t.tx0, t.py, t.px, t.Hp,
-                                     t.Wp, wave, j, h, tr);
+    if (LDSW)
+        conv_exp_store_lds<TW, 3, 3, TW + 2>(a, ximg, yimg, P, a.wc, WE, BNV, t.TH, t.ty0, t.tx0, t.py, t.px,
+                                             t.Hp, t.Wp, wave, j, h, tr);
+    else
+        conv_exp_store<TW, 3, 3, TW + 2>(a, ximg, yimg, P, a.wc, t.TH, t.ty0, t.tx0, t.py, t.px, t.Hp,
+                                         t.Wp, wave, j, h, tr);
 #ifdef SSAL_PHASE_TRACE
     __builtin_amdgcn_s_waitcnt(0);  // mark 7 = all stores acknowledged
 #endif
@@ -629,128 +706,212 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck_mfma_asym(BnkArgs a)
 
 constexpr int CDN = 64;  // input channels of the downsample block
 
+// Structure (same recipe as k_bottleneck16): the tile's CENTRE output pixels are projected with the
+// (wave, M-tile, lane) mapping phase B uses, so the 2x2 input patches the projection loads are exactly the
+// pooling windows of the residual: the first-max pooling and its window codes are evaluated on the fly
+// while the four taps stream through (codes stored at once, 32 pooled values per lane and M-tile kept in
+// registers) -- the block input is read once.  The expansion is evaluated as D[co][pixel] (lane = pixel,
+// 4 consecutive channels per register group): float4 stores, residual of N-tiles 0/1 straight from the
+// pooled registers.  Expansion kernel and BN vectors live in LDS, the projection kernel streams from L1
+// through a window of WIN k-pair steps; activation fragments are double-buffered per tap.
 template <int TW>
 __global__ __launch_bounds__(256, 2) void k_downsample_mfma(DownArgs a)
 {
+    constexpr int TH = 8, HW2 = TW + 2;
+    constexpr int MPW = (TH * TW) / 32 / 4;  // centre M-tiles per wave: 2 (TW 32) or 1 (TW 16)
+    constexpr int RING = 2 * HW2 + 2 * TH;   // 84 / 52
+    constexpr int NRMT = (RING + 31) / 32;   // ring M-tiles: wave w < NRMT projects ring tile w
+    constexpr int QDUMP = PMAX - 1;          // spare P row for M-tile pixels beyond the ring
     __shared__ float P[PMAX * PSTR];
+    __shared__ float WE[F * C];              // expansion kernel [ci][co]
+    __shared__ float BNV[3 * C];             // es | et | ra
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
-    constexpr int HW2 = TW + 2;
     const int Ho = a.H / 2, Wo = a.W / 2;
     int b = blockIdx.x;
     const int tx = b % a.tiles_x; b /= a.tiles_x;
     const int ty = b % a.tiles_y; b /= a.tiles_y;
     const int n = b;
-    const int TH = a.TH;
     const int ty0 = ty * TH, tx0 = tx * TW;
     const float *ximg = a.x + (long)n * a.H * a.W * CDN;
     float *yimg = a.y + (long)n * Ho * Wo * C;
     uint8_t *cimg = a.code + (long)n * Ho * Wo * CDN;
 
-    // ---- phase A: 2x2/s2 projection of the halo'd output tile -> LDS ----------------------------
-    {
-        const float bs = a.ps[j], bt = a.pt[j], ba = a.pa[j];
-        const int npix_halo = (TH + 2) * HW2;
-        const int nmt = (npix_halo + 31) / 32;
-        for (int mt = wave; mt < nmt; mt += 4) {
-            const int q = mt * 32 + j;
-            const int hr = q / HW2, hc = q - hr * HW2;
-            const int pr = ty0 - 1 + hr, pc = tx0 - 1 + hc;
-            const bool valid = (q < npix_halo) && (pr >= 0) && (pr < Ho) && (pc >= 0) && (pc < Wo);
-            const unsigned long long vmask = __ballot(valid);
-            if (vmask == 0ull) {
+    for (int i = threadIdx.x; i < F * C / 4; i += 256)
+        reinterpret_cast<float4 *>(WE)[i] = reinterpret_cast<const float4 *>(a.we)[i];
+    if (threadIdx.x < 3 * C / 4) {
+        const int arr = threadIdx.x / (C / 4), k4 = threadIdx.x % (C / 4);
+        const float *src = arr == 0 ? a.es : arr == 1 ? a.et : a.ra;
+        reinterpret_cast<float4 *>(BNV)[threadIdx.x] = reinterpret_cast<const float4 *>(src)[k4];
+    }
+
+    // ---- phase A: 2x2/s2 projection (K = 4 taps x 64 ci) -----------------------------------------------
+    constexpr int WIN = 8;                   // k-pair steps per weight window; 32 steps per tap
+    const rsrc_t wrs = make_rsrc(a.wp, 4 * CDN * F * 4);
+    const unsigned wlo = (unsigned)lane * 4u;  // fragment s of lane l = Wp[64 s + l]  (rows 2s, 2s+1)
+    const float bs = a.ps[j], bt = a.pt[j], ba = a.pa[j];
+    auto q_ring = [&](int u) {  // halo'd-tile index of ring pixel u (branch-free)
+        const int k = u - 2 * HW2;
+        const int side = (1 + (k >> 1)) * HW2 + ((k & 1) ? HW2 - 1 : 0);
+        const int q = u < HW2 ? u : (u < 2 * HW2 ? (TH + 1) * HW2 + (u - HW2) : side);
+        return u < RING ? q : QDUMP;
+    };
+    auto load_tap = [&](const float *xp, int tap, float4 (&v)[8]) {  // lane half h: channels 8m + 4h .. +3
+        const float *xt = xp + ((tap >> 1) * a.W + (tap & 1)) * CDN + 4 * h;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int qi = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    P[qi * PSTR + j] = 0.0f;
-                }
-                continue;
+        for (int m = 0; m < 8; ++m) v[m] = *reinterpret_cast<const float4 *>(xt + 8 * m);
+    };
+    // one M-tile: 4 taps x 32 k-pair steps; POOL: track the first maximum of the window and its code
+    auto project = [&](const float *xp, unsigned vmask, auto qf, bool pool, float4 (&best)[8], unsigned (&code)[8]) {
+        f32x16 acc = {0};
+        float4 va[8], vb[8];
+        float wa[WIN], wb[WIN];
+        auto fetch_w = [&](int s0, float (&w)[WIN]) {
+#pragma unroll
+            for (int s = 0; s < WIN; ++s) w[s] = bload(wrs, wlo, (s0 + s) * 256);
+        };
+        auto steps = [&](const float4 (&v)[8], int m0, const float (&w)[WIN]) {  // WIN / 4 fragments
+#pragma unroll
+            for (int u = 0; u < WIN / 4; ++u) {
+                float a0 = v[m0 + u].x, a1 = v[m0 + u].y, a2 = v[m0 + u].z, a3 = v[m0 + u].w;
+                swap32(a0, a1);
+                swap32(a2, a3);
+                acc = mfma32(a0, w[4 * u + 0], acc);
+                acc = mfma32(a2, w[4 * u + 1], acc);
+                acc = mfma32(a1, w[4 * u + 2], acc);
+                acc = mfma32(a3, w[4 * u + 3], acc);
             }
-            const float *xp = valid ? ximg + ((long)(2 * pr) * a.W + 2 * pc) * CDN : ximg;
-            f32x16 acc = {0};
-#pragma unroll 1
-            for (int tap = 0; tap < 4; ++tap) {  // (dy,dx) ascending == (kh,kw) order of the oracle
-                const float *xt = xp + ((tap >> 1) * a.W + (tap & 1)) * CDN;
-                float4 v[8];
+        };
+        auto pool_tap = [&](const float4 (&v)[8], int tap) {  // strict '>' in (dy,dx) order: first maximum wins
 #pragma unroll
-                for (int m = 0; m < 8; ++m)
-                    v[m] = *reinterpret_cast<const float4 *>(xt + (2 * m + h) * 4);
-                float wf[32];
-#pragma unroll
-                for (int k = 0; k < 32; ++k) wf[k] = a.wp[(tap * CDN + 2 * k + h) * F + j];
-#pragma unroll
-                for (int m = 0; m < 8; ++m) {
-                    float a0 = v[m].x, a1 = v[m].y, a2 = v[m].z, a3 = v[m].w;
-                    swap32(a0, a1);
-                    swap32(a2, a3);
-                    acc = mfma32(a0, wf[4 * m + 0], acc);
-                    acc = mfma32(a2, wf[4 * m + 1], acc);
-                    acc = mfma32(a1, wf[4 * m + 2], acc);
-                    acc = mfma32(a3, wf[4 * m + 3], acc);
-                }
+            for (int m = 0; m < 8; ++m) {
+                if (tap == 0) { best[m] = v[m]; code[m] = 0u; continue; }
+                const unsigned cd = (unsigned)tap;
+                if (v[m].x > best[m].x) { best[m].x = v[m].x; code[m] = (code[m] & 0xFFFFFF00u) | cd; }
+                if (v[m].y > best[m].y) { best[m].y = v[m].y; code[m] = (code[m] & 0xFFFF00FFu) | (cd << 8); }
+                if (v[m].z > best[m].z) { best[m].z = v[m].z; code[m] = (code[m] & 0xFF00FFFFu) | (cd << 16); }
+                if (v[m].w > best[m].w) { best[m].w = v[m].w; code[m] = (code[m] & 0x00FFFFFFu) | (cd << 24); }
+                // pin the code update here: left free, LLVM sinks it to the store after the M-tile and keeps
+                // the 96 compare masks of an M-tile alive in (spilled) SGPR pairs instead
+                asm volatile("" : "+v"(code[m]));
             }
+        };
+        auto run_tap = [&](const float4 (&v)[8], int tap) {  // 32 steps = 4 windows; the window after next is in flight
+            fetch_w(tap * 32 + WIN, wb);
+            __builtin_amdgcn_sched_barrier(0);
+            steps(v, 0, wa);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_w(tap * 32 + 2 * WIN, wa);
+            __builtin_amdgcn_sched_barrier(0);
+            steps(v, 2, wb);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_w(tap * 32 + 3 * WIN, wb);
+            __builtin_amdgcn_sched_barrier(0);
+            steps(v, 4, wa);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap < 3) fetch_w(tap * 32 + 4 * WIN, wa);
+            __builtin_amdgcn_sched_barrier(0);
+            steps(v, 6, wb);
+            __builtin_amdgcn_sched_barrier(0);
+            if (pool) pool_tap(v, tap);
+        };
+        load_tap(xp, 0, va);
+        fetch_w(0, wa);
+        load_tap(xp, 1, vb);
+        run_tap(va, 0);
+        load_tap(xp, 2, va);
+        run_tap(vb, 1);
+        load_tap(xp, 3, vb);
+        run_tap(va, 2);
+        run_tap(vb, 3);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int ri = (i & 3) + 8 * (i >> 2) + 4 * h;
-                const bool ok = (vmask >> ri) & 1ull;
-                P[(mt * 32 + ri) * PSTR + j] = ok ? prelu1(fmaf(acc[i], bs, bt), ba) : 0.0f;
-            }
+        for (int i = 0; i < 16; ++i) {  // rows = pixels (registers), cols = co (lanes)
+            const int ri = (i & 3) + 8 * (i >> 2) + 4 * h;
+            const bool ok = (vmask >> ri) & 1u;
+            P[qf(ri) * PSTR + j] = ok ? prelu1(fmaf(acc[i], bs, bt), ba) : 0.0f;  // exact zero outside the image
+        }
+    };
+
+    float4 pooled[MPW][8];  // max-pooled input, channels 8m + 4h .. +3 of the lane's centre pixel
+    long opixk[MPW];        // output pixel index of the lane's centre pixel, -1 outside the image
+    if (wave < NRMT) {      // wave-uniform: this wave's ring tile
+        const int u = wave * 32 + j;
+        const int q = q_ring(u);
+        const int pr = ty0 - 1 + q / HW2, pc = tx0 - 1 + q % HW2;
+        const bool rvalid = (u < RING) && pr >= 0 && pr < Ho && pc >= 0 && pc < Wo;
+        const float *xp = rvalid ? ximg + ((long)(2 * pr) * a.W + 2 * pc) * CDN : ximg;
+        float4 dummy_best[8];
+        unsigned dummy_code[8];
+        project(xp, (unsigned)__ballot(rvalid), [&](int ri) { return q_ring(wave * 32 + ri); }, false, dummy_best,
+                dummy_code);
+    }
+#pragma unroll
+    for (int k = 0; k < MPW; ++k) {
+        const int mt = wave + 4 * k;
+        const int tt = mt * 32 + j;
+        const int oy = ty0 + tt / TW, ox = tx0 + tt % TW;
+        const bool valid = oy < Ho && ox < Wo;
+        opixk[k] = valid ? (long)oy * Wo + ox : -1;
+        const float *xp = valid ? ximg + ((long)(2 * oy) * a.W + 2 * ox) * CDN : ximg;
+        unsigned code[8];
+        project(xp, (unsigned)__ballot(valid),
+                [&](int ri) { const int t2 = mt * 32 + ri; return (t2 / TW + 1) * HW2 + (t2 % TW) + 1; }, true,
+                pooled[k], code);
+        if (valid) {  // window codes dy*2+dx of channels 8m + 4h .. +3: 4 bytes per store
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+                *reinterpret_cast<unsigned *>(cimg + opixk[k] * CDN + 8 * m + 4 * h) = code[m];
         }
     }
     __syncthreads();
 
-    // ---- phase B: 3x3 conv, expansion to 128, pooled residual (+ codes), PReLU --------------------
-    const int nmt_out = (TH * TW) / 32;
-    for (int mt = wave; mt < nmt_out; mt += 4) {
+    // ---- phase B: 3x3 conv -> expansion D[co][pixel] -> + pooled residual (registers) -> float4 stores ----
+    const float *wel = WE + h * C + j;  // We[2s + h][nt*32 + j] = wel[2s*C + nt*32]
+    const float *bnl = BNV + 4 * h;     // vectors of channels nt*32 + 8g + 4h .. +3
+#pragma unroll
+    for (int k = 0; k < MPW; ++k) {
+        const int mt = wave + 4 * k;
         float qv[16];
         conv_tile_q<TW, 3, 3, HW2>(a, P, a.wc, mt, j, h, qv);
-        int ooff[16], xoff[16];
-        unsigned okmask = 0;
+        float *yp = yimg + (opixk[k] >= 0 ? opixk[k] : 0) * C + 4 * h;
+        auto chain = [&](int nt, int s, f32x16 e) { return mfma32(wel[2 * s * C + nt * 32], qv[ord(s)], e); };
+        auto epilogue = [&](int nt, int g, const f32x16 &e) {
+            const float4 s4 = *reinterpret_cast<const float4 *>(bnl + nt * 32 + 8 * g);
+            const float4 t4 = *reinterpret_cast<const float4 *>(bnl + C + nt * 32 + 8 * g);
+            const float4 a4 = *reinterpret_cast<const float4 *>(bnl + 2 * C + nt * 32 + 8 * g);
+            const float4 x4 = nt < 2 ? pooled[k][(4 * nt + g) & 7] : make_float4(0.f, 0.f, 0.f, 0.f);  // channels >= 64: zero padding
+            float4 o;
+            o.x = prelu1(fmaf(e[4 * g + 0], s4.x, t4.x) + x4.x, a4.x);
+            o.y = prelu1(fmaf(e[4 * g + 1], s4.y, t4.y) + x4.y, a4.y);
+            o.z = prelu1(fmaf(e[4 * g + 2], s4.z, t4.z) + x4.z, a4.z);
+            o.w = prelu1(fmaf(e[4 * g + 3], s4.w, t4.w) + x4.w, a4.w);
+            if (opixk[k] >= 0) *reinterpret_cast<float4 *>(yp + nt * 32 + 8 * g) = o;
+        };
+        f32x16 e0 = {0}, e1 = {0};
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int ti = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            const int rr = ti / TW, cc = ti - rr * TW;
-            const int oy = ty0 + rr, ox = tx0 + cc;
-            const bool ok = (oy < Ho) && (ox < Wo);
-            okmask |= ok ? (1u << i) : 0u;
-            ooff[i] = ok ? oy * Wo + ox : 0;                      // output pixel index
-            xoff[i] = ok ? ((2 * oy) * a.W + 2 * ox) * CDN : 0;  // top-left of the pooling window
+        for (int s = 0; s < 16; ++s) e0 = chain(0, s, e0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int s = 4 * g; s < 4 * g + 4; ++s) e1 = chain(1, s, e1);
+            epilogue(0, g, e0);
         }
-#pragma unroll 1
-        for (int nt = 0; nt < 4; ++nt) {
-            const int co = nt * 32 + j;
-            float wef[16];
+        e0 = (f32x16){0};
 #pragma unroll
-            for (int k = 0; k < 16; ++k) wef[k] = a.we[(2 * k + h) * C + co];
-            float rx[16];
-            if (nt < 2) {  // channels < 64 carry the pooled input; wave-uniform branch
+        for (int g = 0; g < 4; ++g) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float *w0 = ximg + xoff[i] + co;
-                    const float v00 = w0[0], v01 = w0[CDN];
-                    const float v10 = w0[(long)a.W * CDN], v11 = w0[(long)a.W * CDN + CDN];
-                    float best = v00;  // strict '>' scan in (dy,dx) order: first maximum wins
-                    int cd = 0;
-                    if (v01 > best) { best = v01; cd = 1; }
-                    if (v10 > best) { best = v10; cd = 2; }
-                    if (v11 > best) { best = v11; cd = 3; }
-                    rx[i] = best;
-                    if ((okmask >> i) & 1u) cimg[ooff[i] * CDN + co] = (uint8_t)cd;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) rx[i] = 0.0f;
-            }
-            f32x16 e = {0};
-#pragma unroll
-            for (int s = 0; s < 16; ++s) e = mfma32(qv[ord(s)], wef[s], e);
-            const float s1 = a.es[co], t1 = a.et[co], al = a.ra[co];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float v = prelu1(fmaf(e[i], s1, t1) + rx[i], al);
-                if ((okmask >> i) & 1u) yimg[(long)ooff[i] * C + co] = v;
-            }
+            for (int s = 4 * g; s < 4 * g + 4; ++s) e0 = chain(2, s, e0);
+            epilogue(1, g, e1);
         }
+        e1 = (f32x16){0};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int s = 4 * g; s < 4 * g + 4; ++s) e1 = chain(3, s, e1);
+            epilogue(2, g, e0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) epilogue(3, g, e1);
     }
 }
 
@@ -1002,7 +1163,6 @@ Knobs &knobs()
         q.bnk_wgs = env("SSAL_BNK_WGS", 3);
         q.bnk_split = env("SSAL_BNK_SPLIT", 0);
         q.bnk_tw = env("SSAL_BNK_TW", 0);
-        q.bnk_delay = env("SSAL_BNK_DELAY", 0);
         q.ablate = env("SSAL_ABLATE", 0);
         return q;
     }();
@@ -1121,7 +1281,6 @@ hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W,
     a.N = N; a.H = H; a.W = W; a.dil = dil;
     const Knobs &kn = knobs();
     a.ablate = kn.ablate;
-    a.delay = kn.bnk_delay;
     a.trace = nullptr;
     if (Cin != C) return launch_bottleneck_mfma16(a, Cin, s);
     a.TH = 8;

@@ -105,7 +105,6 @@ struct Knobs {
     int bnk_wgs;     // design 1: workgroups per CU the register budget is held to (2 or 3)
     int bnk_split;   // design 1: anti-phase half tiles for the second dispatch slot of every CU
     int bnk_tw;      // 16 = force 8x16 tiles
-    int bnk_delay;   // shader clocks workgroups 256..511 spin before starting (experiment)
     int ablate;      // 1 = stop after the projection phase, 2 = skip it (timing only, results invalid)
 };
 Knobs &knobs();

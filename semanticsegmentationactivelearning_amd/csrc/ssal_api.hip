@@ -1095,10 +1095,7 @@ SSAL_API int ssal_debug_set_knob(const char *name, int value)
     if (!name) return fail(SSAL_EINVAL, "NULL knob name");
     ssal::Knobs &k = ssal::knobs();
     const std::string n(name);
-    if (n == "bnk_design") k.bnk_design = value;
-    else if (n == "bnk_wgs") k.bnk_wgs = value;
-    else if (n == "bnk_split") k.bnk_split = value;
-    else if (n == "bnk_tw") k.bnk_tw = value;
+    if (n == "bnk_tw") k.bnk_tw = value;
     else if (n == "ablate") k.ablate = value;
     else return fail(SSAL_EINVAL, "unknown knob");
     return SSAL_OK;

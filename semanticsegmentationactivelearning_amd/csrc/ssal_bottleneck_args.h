@@ -19,9 +19,6 @@ struct BnkArgs {
     int TH;                // tile rows (phase space)
     int tiles_y, tiles_x;  // tiles per phase sub-image (sized for the largest phase)
     unsigned long long *trace;  // phase-trace buffer (NULL unless a -DSSAL_PHASE_TRACE build is being traced)
-    int ntiles;            // N * dil^2 * tiles_y * tiles_x
-    int split_lo, split_hi;  // tiles in [split_lo, split_hi) are processed as two 4-row half tiles: workgroup
-                             // `tile` takes the top half, workgroup ntiles + (tile - split_lo) the bottom half
     int ablate;            // measurement aid (SSAL_ABLATE env): 1 = stop after the projection phase,
                            // 2 = skip the projection phase (results invalid; timing only)
 };

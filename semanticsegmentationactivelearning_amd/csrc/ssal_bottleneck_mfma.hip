@@ -134,21 +134,39 @@ __device__ __forceinline__ void conv5x1_to_lds(const BnkArgs &a, const float *P,
     for (int mt = wave; mt < nmt; mt += 4) {
         const int u = mt * 32 + j;
         f32x16 acc = {0};
-#pragma unroll 1
-        for (int kh = 0; kh < 5; ++kh) {
-            const float *pq = P + (u + (r0 + kh) * HWP) * PSTR + 2 * h;  // pixel (r0 + r + kh, c')
-            float w[16];
+        // one tap ahead, as in conv_tile_q: kernel fragments (L1/L2) and LDS fragments of tap kh+1 are
+        // requested before the 16 MFMAs of tap kh
+        float wA[16], wB[16];
+        float2 pA[8], pB[8];
+        auto load_tap = [&](int kh, float (&w)[16], float2 (&pv)[8]) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) w[k] = bload(wrs, lo, kh * (F * F * 4) + k * 256);  // W0[kh][2k + h][j]
+            const float *pq = P + (u + (r0 + kh) * HWP) * PSTR + 2 * h;  // pixel (r0 + r + kh, c')
+#pragma unroll
+            for (int sq = 0; sq < 8; ++sq) pv[sq] = *reinterpret_cast<const float2 *>(pq + 4 * sq);
+        };
+        auto run_tap = [&](const float (&w)[16], const float2 (&pv)[8]) {
 #pragma unroll
             for (int sq = 0; sq < 8; ++sq) {
-                float2 pv = *reinterpret_cast<const float2 *>(pq + 4 * sq);
-                float a0 = pv.x, a1 = pv.y;
+                float a0 = pv[sq].x, a1 = pv[sq].y;
                 swap32(a0, a1);  // a0 = ci(4sq | 4sq+1), a1 = ci(4sq+2 | 4sq+3)
                 acc = mfma32(a0, w[2 * sq], acc);
                 acc = mfma32(a1, w[2 * sq + 1], acc);
             }
+        };
+        load_tap(0, wA, pA);
+#pragma unroll 1
+        for (int kh = 0; kh + 1 < 5; kh += 2) {
+            load_tap(kh + 1, wB, pB);
+            __builtin_amdgcn_sched_barrier(0);
+            run_tap(wA, pA);
+            __builtin_amdgcn_sched_barrier(0);
+            load_tap(kh + 2, wA, pA);
+            __builtin_amdgcn_sched_barrier(0);
+            run_tap(wB, pB);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        run_tap(wA, pA);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int ri = (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -317,71 +335,6 @@ __device__ __forceinline__ void conv_exp_store(const BnkArgs &a, const float *xi
     }
 }
 
-// ---- the same phase with the expansion operands in LDS (WE = We[ci][co], BNV = es | et | ra): the only
-// global loads of the phase are the conv kernel fragments and the residual, and ALL 64 residual values of
-// an M-tile are requested in one go right after the conv (whose kernel fragments are ahead of them in the
-// in-order vmcnt queue), so the epilogues wait for HBM once per M-tile instead of once per N-tile.
-template <int TW, int KH, int KW, int SW>
-__device__ __forceinline__ void conv_exp_store_lds(const BnkArgs &a, const float *ximg, float *yimg,
-                                                   const float *S, const float *wconv, const float *WE,
-                                                   const float *BNV, int TH, int ty0, int tx0, int py, int px,
-                                                   int Hp, int Wp, int wave, int j, int h, PhaseTrace &tr)
-{
-    const int d = a.dil;
-    const int nmt_out = (TH * TW) / 32;
-    int trk = 3;
-    constexpr unsigned kOOB = 0x80000000u;
-    const unsigned img_bytes = (unsigned)(a.H * a.W * C) * 4u;
-    const rsrc_t xrs = make_rsrc(ximg, img_bytes), yrs = make_rsrc(yimg, img_bytes);
-    const float *wel = WE + h * C + j;  // We[2s + h][nt*32 + j] = wel[2s*C + nt*32]
-    for (int mt = wave; mt < nmt_out; mt += 4) {
-        float qv[16];
-        conv_tile_q<TW, KH, KW, SW>(a, S, wconv, mt, j, h, qv);
-        tr.mark(trk++);
-        unsigned boff[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int ti = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            const int rr = ti / TW, cc = ti - rr * TW;
-            const int pr = ty0 + rr, pc = tx0 + cc;
-            const bool ok = (pr < Hp) && (pc < Wp);
-            boff[i] = ok ? (unsigned)((((py + pr * d) * a.W + (px + pc * d)) * C + j) * 4) : kOOB;
-        }
-        float rx[4][16];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) rx[nt][i] = bload(xrs, boff[i], nt * 128);
-        __builtin_amdgcn_sched_barrier(0);
-        auto chain = [&](int nt, int s0, f32x16 e) {
-#pragma unroll
-            for (int s = s0; s < s0 + 4; ++s) e = mfma32(qv[ord(s)], wel[2 * s * C + nt * 32], e);
-            return e;
-        };
-        auto epi = [&](int nt, int i0, const f32x16 &e) {
-            const float s1 = BNV[nt * 32 + j], t1 = BNV[C + nt * 32 + j], al = BNV[2 * C + nt * 32 + j];
-#pragma unroll
-            for (int i = i0; i < i0 + 4; ++i)
-                __builtin_amdgcn_raw_buffer_store_b32(
-                    __builtin_bit_cast(unsigned, prelu1(fmaf(e[i], s1, t1) + rx[nt][i], al)), yrs, boff[i], nt * 128, 0);
-        };
-        f32x16 e0 = {0}, e1 = {0};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) e0 = chain(0, 4 * q, e0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { e1 = chain(1, 4 * q, e1); epi(0, 4 * q, e0); }
-        e0 = (f32x16){0};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { e0 = chain(2, 4 * q, e0); epi(1, 4 * q, e1); }
-        e1 = (f32x16){0};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { e1 = chain(3, 4 * q, e1); epi(2, 4 * q, e0); }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) epi(3, 4 * q, e1);
-        tr.mark(trk++);
-    }
-}
-
 struct TileId {
     int n, py, px, ty0, tx0, Hp, Wp, TH;
     bool empty;
@@ -393,18 +346,7 @@ __device__ __forceinline__ TileId decode_tile(const BnkArgs &a)
     TileId t;
     const int d = a.dil;
     int b = blockIdx.x;
-    // Anti-phase scheduling (see launch_bottleneck_mfma): the workgroups that fill the SECOND slot of every
-    // CU in the first dispatch round get half-height tiles, so from then on the two co-resident workgroups
-    // of a CU run half a tile apart -- one streams its input while the other one is on the matrix cores.
     t.TH = a.TH;
-    int row0 = 0;
-    if (b >= a.ntiles) {  // bottom half of a split tile
-        b = a.split_lo + (b - a.ntiles);
-        t.TH = a.TH / 2;
-        row0 = a.TH / 2;
-    } else if (b >= a.split_lo && b < a.split_hi) {  // top half
-        t.TH = a.TH / 2;
-    }
     const int tx = b % a.tiles_x; b /= a.tiles_x;
     const int ty = b % a.tiles_y; b /= a.tiles_y;
     t.px = b % d; b /= d;
@@ -412,21 +354,17 @@ __device__ __forceinline__ TileId decode_tile(const BnkArgs &a)
     t.n = b;
     t.Hp = (a.H - t.py + d - 1) / d;  // rows / cols of this phase sub-image
     t.Wp = (a.W - t.px + d - 1) / d;
-    t.ty0 = ty * a.TH + row0;
+    t.ty0 = ty * a.TH;
     t.tx0 = tx * TW;
     t.empty = (t.ty0 >= t.Hp) || (t.tx0 >= t.Wp);
     return t;
 }
 
-// regular / dilated 3x3 bottleneck.  WGS = workgroups per CU the register budget is held to: 3 (168
-// VGPRs, 3 x 47 KB of LDS) is the shipping configuration; 2 is kept for A/B runs (SSAL_BNK_WGS=2).
-template <int TW, int WGS>
-__global__ __launch_bounds__(256, WGS) void k_bottleneck_mfma(BnkArgs a)
+// regular / dilated 3x3 bottleneck: 168 VGPRs and 47 KB of LDS = three workgroups per CU
+template <int TW>
+__global__ __launch_bounds__(256, 3) void k_bottleneck_mfma(BnkArgs a)
 {
     __shared__ float P[PMAX * PSTR];
-    constexpr bool LDSW = WGS == 2;  // two workgroups per CU leave LDS room for the expansion operands
-    __shared__ float WE[LDSW ? F * C : 1];
-    __shared__ float BNV[LDSW ? 3 * C : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const TileId t = decode_tile<TW>(a);
@@ -435,229 +373,14 @@ __global__ __launch_bounds__(256, WGS) void k_bottleneck_mfma(BnkArgs a)
     tr.mark(0);
     const float *ximg = a.x + (long)t.n * a.H * a.W * C;
     float *yimg = a.y + (long)t.n * a.H * a.W * C;
-    if (LDSW) {
-        for (int i = threadIdx.x; i < F * C / 4; i += 256)
-            reinterpret_cast<float4 *>(WE)[i] = reinterpret_cast<const float4 *>(a.we)[i];
-        if (threadIdx.x < 3 * C / 4) {
-            const int arr = threadIdx.x / (C / 4), k4 = threadIdx.x % (C / 4);
-            const float *src = arr == 0 ? a.es : arr == 1 ? a.et : a.ra;
-            reinterpret_cast<float4 *>(BNV)[threadIdx.x] = reinterpret_cast<const float4 *>(src)[k4];
-        }
-    }
     if (a.ablate != 2)
         proj_to_lds<TW, 1>(a, ximg, P, t.TH, t.ty0, t.tx0, t.py, t.px, t.Hp, t.Wp, wave, j, h);
     tr.mark(1);
     __syncthreads();
     tr.mark(2);
     if (a.ablate == 1) return;
-    if (LDSW)
-        conv_exp_store_lds<TW, 3, 3, TW + 2>(a, ximg, yimg, P, a.wc, WE, BNV, t.TH, t.ty0, t.tx0, t.py, t.px,
-                                             t.Hp, t.Wp, wave, j, h, tr);
-    else
-        conv_exp_store<TW, 3, 3, TW + 2>(a, ximg, yimg, P, a.wc, t.TH, t.ty0, t.tx0, t.py, t.px, t.Hp,
-                                         t.Wp, wave, j, h, tr);
-#ifdef SSAL_PHASE_TRACE
-    __builtin_amdgcn_s_waitcnt(0);  // mark 7 = all stores acknowledged
-#endif
-    tr.mark(7);
-    tr.flush(a.trace, lane, wave);
-}
-
-// ---- regular / dilated 3x3 bottleneck, second design: the block input is read ONCE -----------------
-// k_bottleneck_mfma re-reads the residual in its expansion epilogue; at batch 8 the per-XCD working set
-// (11 MB) does not fit the 4 MB L2, so that re-read goes to the fabric (426 MB moved per launch against
-// 268 MB algorithmic) and the kernel sits at the memory roof of this access pattern.  Here the tile's
-// CENTRE pixels are projected with the (wave, M-tile, lane) mapping phase B uses and the expansion is
-// evaluated as D[co][pixel] (lane = pixel): the float4 activation fragments phase A loads (channels
-// 8u + 4h .. +3 of the lane's pixel) are then exactly the residual of output registers 4g .. 4g+3 of
-// N-tile nt = u / 4, g = u % 4 -- they stay in registers (2 x 64 per lane), the one-pixel halo ring is
-// projected separately, and the output leaves as one float4 per lane and register group.
-// The expansion kernel and its BN / PReLU vectors live in LDS: phase B issues no global load after its
-// first store, so stores never sit in front of a load in the in-order vmcnt queue.
-template <int TW>
-__global__ __launch_bounds__(256, 2) void k_bottleneck_mfma_r(BnkArgs a)
-{
-    constexpr int TH = 8, HWP = TW + 2;
-    constexpr int MPW = (TH * TW) / 32 / 4;  // centre M-tiles per wave: 2 (TW 32) or 1 (TW 16)
-    constexpr int RING = 2 * HWP + 2 * TH;   // halo ring pixels: 84 or 52
-    constexpr int NRMT = (RING + 31) / 32;   // ring M-tiles (3 or 2): wave w < NRMT projects ring tile w
-    constexpr unsigned kOOB = 0x80000000u;   // byte offset the buffer range check always rejects
-    __shared__ float P[PMAX * PSTR];
-    __shared__ float WE[F * C];              // expansion kernel [ci][co]
-    __shared__ float BNV[3 * C];             // es | et | ra
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = lane & 31, h = lane >> 5;
-    const TileId t = decode_tile<TW>(a);
-    if (t.empty) return;  // whole workgroup: no barrier has been reached yet
-    PhaseTrace tr;
-    tr.mark(0);
-    const int d = a.dil;
-    const float *ximg = a.x + (long)t.n * a.H * a.W * C;
-    float *yimg = a.y + (long)t.n * a.H * a.W * C;
-    const unsigned img_bytes = (unsigned)(a.H * a.W * C) * 4u;
-    const rsrc_t xrs = make_rsrc(ximg, img_bytes), yrs = make_rsrc(yimg, img_bytes);
-    auto pix_off = [&](int pr, int pc) {  // byte offset of phase-space pixel (pr, pc) in image n, + this half's 16 B
-        return (unsigned)(((t.py + pr * d) * a.W + (t.px + pc * d)) * C + 4 * h) * 4u;
-    };
-
-    // ---- stage the expansion operands in LDS (visible after the barrier) ---------------------------
-    for (int i = threadIdx.x; i < F * C / 4; i += 256)
-        reinterpret_cast<float4 *>(WE)[i] = reinterpret_cast<const float4 *>(a.we)[i];
-    if (threadIdx.x < 3 * C / 4) {
-        const int arr = threadIdx.x / (C / 4), k4 = threadIdx.x % (C / 4);
-        const float *src = arr == 0 ? a.es : arr == 1 ? a.et : a.ra;
-        reinterpret_cast<float4 *>(BNV)[threadIdx.x] = reinterpret_cast<const float4 *>(src)[k4];
-    }
-
-    // ---- phase A ------------------------------------------------------------------------------------
-    // Every activation fragment of the wave (ring tile + MPW centre tiles: 3 x 64 registers) is requested
-    // up front -- ONE exposed HBM latency per workgroup; the projection kernel is streamed from L1 through
-    // a rolling window of WIN k-pair steps instead of living in registers (rows 2s, 2s+1 of Wp = 64
-    // consecutive floats: fragment s of lane l = Wp[64 s + l]).
-    constexpr int WIN = 8;
-    const rsrc_t wrs = make_rsrc(a.wp, C * F * 4);
-    const unsigned wlo = (unsigned)lane * 4u;
-    const float bs = a.ps[j], bt = a.pt[j], ba = a.pa[j];
-
-    auto load_frags = [&](unsigned off, float4 (&X)[16]) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) X[u] = bload4(xrs, off, u * 32);  // channels 8u + 4h .. +3
-    };
-    // project the 32 pixels of one M-tile (vmask: in-image pixels; qf(ri): P row of M-tile pixel ri)
-    auto project = [&](const float4 (&X)[16], unsigned vmask, auto qf) {
-        f32x16 acc = {0};
-        float wa[WIN], wb[WIN];
-        auto fetch_w = [&](int s0, float (&w)[WIN]) {
-#pragma unroll
-            for (int s = 0; s < WIN; ++s) w[s] = bload(wrs, wlo, (s0 + s) * 256);
-        };
-        auto steps = [&](int s0, const float (&w)[WIN]) {  // WIN k-pair steps = WIN / 4 activation fragments
-#pragma unroll
-            for (int v = 0; v < WIN / 4; ++v) {
-                const int u = s0 / 4 + v;
-                float a0 = X[u].x, a1 = X[u].y, a2 = X[u].z, a3 = X[u].w;
-                swap32(a0, a1);  // a0 = ch(8u+0 | 8u+1), a1 = ch(8u+4 | 8u+5)
-                swap32(a2, a3);  // a2 = ch(8u+2 | 8u+3), a3 = ch(8u+6 | 8u+7)
-                acc = mfma32(a0, w[4 * v + 0], acc);
-                acc = mfma32(a2, w[4 * v + 1], acc);
-                acc = mfma32(a1, w[4 * v + 2], acc);
-                acc = mfma32(a3, w[4 * v + 3], acc);
-            }
-        };
-        fetch_w(0, wa);
-#pragma unroll
-        for (int s0 = 0; s0 < 64; s0 += 2 * WIN) {
-            fetch_w(s0 + WIN, wb);
-            __builtin_amdgcn_sched_barrier(0);
-            steps(s0, wa);
-            __builtin_amdgcn_sched_barrier(0);
-            if (s0 + 2 * WIN < 64) fetch_w(s0 + 2 * WIN, wa);
-            __builtin_amdgcn_sched_barrier(0);
-            steps(s0 + WIN, wb);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {  // rows = pixels (registers), cols = co (lanes)
-            const int ri = (i & 3) + 8 * (i >> 2) + 4 * h;
-            const int q = qf(ri);
-            const bool ok = (vmask >> ri) & 1u;
-            const float v = ok ? prelu1(fmaf(acc[i], bs, bt), ba) : 0.0f;  // exact zero outside the image
-            P[q * PSTR + j] = v;
-        }
-    };
-    constexpr int QDUMP = PMAX - 1;  // spare P row: where M-tile pixels beyond the ring are written
-    auto q_ring = [&](int u) {       // halo'd-tile index of ring pixel u (branch-free)
-        const int k = u - 2 * HWP;
-        const int side = (1 + (k >> 1)) * HWP + ((k & 1) ? HWP - 1 : 0);
-        const int q = u < HWP ? u : (u < 2 * HWP ? (TH + 1) * HWP + (u - HWP) : side);
-        return u < RING ? q : QDUMP;
-    };
-
-    float4 xk[MPW][16];  // centre activation fragments == residual of phase B
-    unsigned offk[MPW];  // byte offset of the lane's pixel (+ 16 h), kOOB outside the image
-#pragma unroll
-    for (int k = 0; k < MPW; ++k) {
-        const int tt = (wave + 4 * k) * 32 + j;
-        const int pr = t.ty0 + tt / TW, pc = t.tx0 + tt % TW;
-        offk[k] = (pr < t.Hp && pc < t.Wp) ? pix_off(pr, pc) : kOOB;
-    }
-    {
-        // ring tile of this wave (waves >= NRMT have none: their offsets are out of range, the loads
-        // return zeros without touching memory) and the first centre tile, requested together
-        float4 XR[16];
-        const int u = wave * 32 + j;
-        const int q = q_ring(u);
-        const int pr = t.ty0 - 1 + q / HWP, pc = t.tx0 - 1 + q % HWP;
-        const bool rvalid = (wave < NRMT) && (u < RING) && pr >= 0 && pr < t.Hp && pc >= 0 && pc < t.Wp;
-        load_frags(rvalid ? pix_off(pr, pc) : kOOB, XR);
-#pragma unroll
-        for (int k = 0; k < MPW; ++k) load_frags(offk[k], xk[k]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (wave < NRMT) {  // wave-uniform
-            const unsigned vmask = (unsigned)__ballot(rvalid);
-            project(XR, vmask, [&](int ri) { return q_ring(wave * 32 + ri); });
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < MPW; ++k) {
-        const int mt = wave + 4 * k;
-        const unsigned vmask = (unsigned)__ballot(offk[k] != kOOB);
-        project(xk[k], vmask, [&](int ri) { const int tt = mt * 32 + ri; return (tt / TW + 1) * HWP + (tt % TW) + 1; });
-    }
-    tr.mark(1);
-    __syncthreads();
-    tr.mark(2);
-
-    // ---- phase B: conv -> expansion D[co][pixel] -> + residual (registers) -> float4 stores ----------
-    const float *wel = WE + h * C + j;          // We[2s + h][nt*32 + j] = wel[2s*C + nt*32]
-    const float *bnl = BNV + 4 * h;             // vectors of channels nt*32 + 8g + 4h .. +3
-#pragma unroll
-    for (int k = 0; k < MPW; ++k) {
-        const int mt = wave + 4 * k;
-        float qv[16];
-        conv_tile_q<TW, 3, 3, HWP>(a, P, a.wc, mt, j, h, qv);
-        tr.mark(3 + 2 * k);
-        auto chain = [&](int nt, int s, f32x16 e) { return mfma32(wel[2 * s * C + nt * 32], qv[ord(s)], e); };
-        auto epilogue = [&](int nt, int g, const f32x16 &e) {
-            const float4 s4 = *reinterpret_cast<const float4 *>(bnl + nt * 32 + 8 * g);
-            const float4 t4 = *reinterpret_cast<const float4 *>(bnl + C + nt * 32 + 8 * g);
-            const float4 a4 = *reinterpret_cast<const float4 *>(bnl + 2 * C + nt * 32 + 8 * g);
-            const float4 x4 = xk[k][4 * nt + g];
-            float4 o;
-            o.x = prelu1(fmaf(e[4 * g + 0], s4.x, t4.x) + x4.x, a4.x);
-            o.y = prelu1(fmaf(e[4 * g + 1], s4.y, t4.y) + x4.y, a4.y);
-            o.z = prelu1(fmaf(e[4 * g + 2], s4.z, t4.z) + x4.z, a4.z);
-            o.w = prelu1(fmaf(e[4 * g + 3], s4.w, t4.w) + x4.w, a4.w);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yrs, offk[k], nt * 128 + g * 32, 0);
-        };
-        // the MFMA chain of N-tile nt+1 is issued interleaved with the epilogue of N-tile nt
-        f32x16 e0 = {0}, e1 = {0};
-#pragma unroll
-        for (int s = 0; s < 16; ++s) e0 = chain(0, s, e0);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-#pragma unroll
-            for (int s = 4 * g; s < 4 * g + 4; ++s) e1 = chain(1, s, e1);
-            epilogue(0, g, e0);
-        }
-        e0 = (f32x16){0};
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-#pragma unroll
-            for (int s = 4 * g; s < 4 * g + 4; ++s) e0 = chain(2, s, e0);
-            epilogue(1, g, e1);
-        }
-        e1 = (f32x16){0};
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-#pragma unroll
-            for (int s = 4 * g; s < 4 * g + 4; ++s) e1 = chain(3, s, e1);
-            epilogue(2, g, e0);
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) epilogue(3, g, e1);
-        tr.mark(4 + 2 * k);
-    }
+    conv_exp_store<TW, 3, 3, TW + 2>(a, ximg, yimg, P, a.wc, t.TH, t.ty0, t.tx0, t.py, t.px, t.Hp,
+                                     t.Wp, wave, j, h, tr);
 #ifdef SSAL_PHASE_TRACE
     __builtin_amdgcn_s_waitcnt(0);  // mark 7 = all stores acknowledged
 #endif
@@ -1142,26 +865,11 @@ hipError_t launch_mfma_peak(int shape, int blocks, int iters, float *out, hipStr
     return hipGetLastError();
 }
 
-static int num_cus()
-{
-    static int n = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-            v = 256;
-        return v;
-    }();
-    return n;
-}
-
 Knobs &knobs()
 {
     static Knobs k = [] {
         auto env = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
         Knobs q;
-        q.bnk_design = env("SSAL_BNK_DESIGN", 1);
-        q.bnk_wgs = env("SSAL_BNK_WGS", 3);
-        q.bnk_split = env("SSAL_BNK_SPLIT", 0);
         q.bnk_tw = env("SSAL_BNK_TW", 0);
         q.ablate = env("SSAL_ABLATE", 0);
         return q;
@@ -1291,18 +999,7 @@ hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W,
     a.tiles_x = (Wp + TW - 1) / TW;
     const long grid = (long)N * dil * dil * a.tiles_y * a.tiles_x;
     if (grid <= 0 || grid > 0x7fffffffL) return hipErrorInvalidValue;
-    a.ntiles = (int)grid;
-    a.split_lo = a.split_hi = 0;
-    long launch_grid = grid;
-    const int design = kn.bnk_design;
-    const bool split_on = !asym && design == 1 && kn.bnk_split && grid >= 2L * num_cus();
-    const int wgs = split_on ? 2 : kn.bnk_wgs;  // anti-phase scheduling assumes exactly two workgroups per CU
-    if (split_on) {
-        a.split_lo = num_cus();
-        a.split_hi = 2 * num_cus();
-        launch_grid = grid + num_cus();
-    }
-    if (g_trace_buf && launch_grid * 4 * 16 * 8 <= g_trace_bytes) a.trace = g_trace_buf;
+    if (g_trace_buf && grid * 4 * 16 * 8 <= g_trace_bytes) a.trace = g_trace_buf;
     const double pix = (double)N * H * W;
     const double f = Cin / 4.0;
     const double taps = asym ? 10.0 : 9.0;
@@ -1315,19 +1012,10 @@ hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W,
         else
             hipLaunchKernelGGL(k_bottleneck_mfma_asym<16>, dim3((unsigned)grid), dim3(256), 0, s, a);
     } else {
-        const dim3 G((unsigned)launch_grid), B(256);
-        if (design == 2 && wide)
-            hipLaunchKernelGGL(k_bottleneck_mfma_r<32>, G, B, 0, s, a);
-        else if (design == 2)
-            hipLaunchKernelGGL(k_bottleneck_mfma_r<16>, G, B, 0, s, a);
-        else if (wide && wgs == 2)
-            hipLaunchKernelGGL((k_bottleneck_mfma<32, 2>), G, B, 0, s, a);
-        else if (wide)
-            hipLaunchKernelGGL((k_bottleneck_mfma<32, 3>), G, B, 0, s, a);
-        else if (wgs == 2)
-            hipLaunchKernelGGL((k_bottleneck_mfma<16, 2>), G, B, 0, s, a);
+        if (wide)
+            hipLaunchKernelGGL(k_bottleneck_mfma<32>, dim3((unsigned)grid), dim3(256), 0, s, a);
         else
-            hipLaunchKernelGGL((k_bottleneck_mfma<16, 3>), G, B, 0, s, a);
+            hipLaunchKernelGGL(k_bottleneck_mfma<16>, dim3((unsigned)grid), dim3(256), 0, s, a);
     }
     return hipGetLastError();
 }

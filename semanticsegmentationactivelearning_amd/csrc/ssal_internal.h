@@ -101,10 +101,7 @@ hipError_t launch_upsample_mfma(const float *x, float *y, const uint8_t *code, i
 // initialised from the SSAL_* environment once, changed at run time with ssal_debug_set_knob for A/B runs
 // and for the tests that compare the variants bit for bit).
 struct Knobs {
-    int bnk_design;  // 1 = residual re-read in the expansion epilogue, 2 = residual kept in registers
-    int bnk_wgs;     // design 1: workgroups per CU the register budget is held to (2 or 3)
-    int bnk_split;   // design 1: anti-phase half tiles for the second dispatch slot of every CU
-    int bnk_tw;      // 16 = force 8x16 tiles
+    int bnk_tw;      // 16 = force 8x16 tiles in the 128-channel bottleneck kernels
     int ablate;      // 1 = stop after the projection phase, 2 = skip it (timing only, results invalid)
 };
 Knobs &knobs();

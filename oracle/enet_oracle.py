@@ -275,3 +275,30 @@ def masked_softmax_cross_entropy(labels, logits, mask, num_classes, weight=0.0, 
     lib.orc_masked_softmax_xent.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float]
     return float(lib.orc_masked_softmax_xent(_p(lg), _p(lab), _p(mk), n, h, w, k, weight, label_smoothing))
+
+
+def resize_nearest_neighbor(x, size):
+    """tf.image.resize_nearest_neighbor, align_corners=False: src = floor(dst * in/out) (float32), clamped"""
+    x = np.asarray(x)
+    h, w = x.shape[1], x.shape[2]
+    oh, ow = int(size[0]), int(size[1])
+    iy = np.minimum(np.floor(np.arange(oh, dtype=np.float32) * (np.float32(h) / np.float32(oh))).astype(np.int64), h - 1)
+    ix = np.minimum(np.floor(np.arange(ow, dtype=np.float32) * (np.float32(w) / np.float32(ow))).astype(np.int64), w - 1)
+    return x[:, iy][:, :, ix]
+
+
+def multiscale_masked_softmax_cross_entropy(labels, logits, mask, num_classes, kernels, weight=0.0,
+                                            label_smoothing=0.0):
+    """tensortools/losses.py:76-157 (forward value): logits[0] = class logits, logits[1:] = lower-scale
+    features, each with its 1x1 head kernels[i] [1,1,C,K]; labels / mask nearest-neighbour resized"""
+    n, h, w, _ = np.asarray(logits[0]).shape
+    lab = np.asarray(labels).reshape(n, h, w)
+    mk = np.asarray(mask, dtype=np.float32).reshape(n, h, w)
+    total = masked_softmax_cross_entropy(lab, logits[0], mk, num_classes, weight, label_smoothing)
+    for feat, krnl in zip(logits[1:], kernels):
+        head = conv2d_same(_f32(feat), _f32(krnl), 1, 1)
+        size = head.shape[1:3]
+        total += masked_softmax_cross_entropy(resize_nearest_neighbor(lab, size), head,
+                                              resize_nearest_neighbor(mk, size), num_classes, weight,
+                                              label_smoothing)
+    return total

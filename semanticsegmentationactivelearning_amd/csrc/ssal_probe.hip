@@ -19,6 +19,32 @@ __global__ __launch_bounds__(256) void k_probe_linear(const float4 *x, float4 *y
 //   FRAG = false: lane l moves bytes [1024 m + 16 l, +16) of the 4 KB group              (fully coalesced)
 //   HALO        : additionally reads the one-pixel ring of the tile (as phase A does), result discarded
 //   SPIN        : shader-clock cycles of dependent ALU work between the loads and the stores
+// mode 9: the same 8 x 32 tile, but each wave moves its four 16-pixel groups one after the other
+// (4 loads, 4 stores, next group) instead of 16 loads followed by 16 stores
+__global__ __launch_bounds__(256) void k_probe_tile_seq(const float *x, float *y, int H, int W)
+{
+    constexpr int C = 64, TH = 8, TW = 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int tiles_x = W / TW, tiles_y = H / TH;
+    int b = blockIdx.x;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y; b /= tiles_y;
+    const float *ximg = x + (long)b * H * W * C;
+    float *yimg = y + (long)b * H * W * C;
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+        const int t0 = (wave + 4 * k) * 16;
+        const int r = t0 / TW, c = t0 % TW;
+        const long off = ((long)(ty * TH + r) * W + tx * TW + c + i16) * C + 4 * g;
+        float4 v[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) v[m] = *reinterpret_cast<const float4 *>(ximg + off + 16 * m);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) *reinterpret_cast<float4 *>(yimg + off + 16 * m) = v[m];
+    }
+}
+
 template <bool FRAG, bool HALO, int TH = 8, int TW = 32>
 __global__ __launch_bounds__(256) void k_probe_tile(const float *x, float *y, int H, int W, int spin)
 {
@@ -86,7 +112,7 @@ hipError_t launch_copy_probe(int mode, const float *x, float *y, int N, int H, i
     const long n = (long)N * H * W * 64;
     static const char *names[] = {"probe linear", "probe tile frag", "probe tile coalesced", "probe tile frag+halo",
                                   "probe tile coalesced+halo"};
-    if (mode < 0 || mode > 8) return hipErrorInvalidValue;
+    if (mode < 0 || mode > 9) return hipErrorInvalidValue;
     ProfScope prof(mode <= 4 ? names[mode] : "probe tile shape", 0.0, 8.0 * n, s);
     const unsigned tiles = (unsigned)((long)N * (H / 8) * (W / 32));
     switch (mode) {
@@ -101,6 +127,7 @@ hipError_t launch_copy_probe(int mode, const float *x, float *y, int N, int H, i
     case 6: hipLaunchKernelGGL((k_probe_tile<true, false, 2, 128>), dim3(tiles), dim3(256), 0, s, x, y, H, W, spin); break;
     case 7: hipLaunchKernelGGL((k_probe_tile<true, false, 1, 256>), dim3(tiles), dim3(256), 0, s, x, y, H, W, spin); break;
     case 8: hipLaunchKernelGGL((k_probe_tile<true, false, 16, 16>), dim3(tiles), dim3(256), 0, s, x, y, H, W, spin); break;
+    case 9: hipLaunchKernelGGL(k_probe_tile_seq, dim3(tiles), dim3(256), 0, s, x, y, H, W); break;
     }
     return hipGetLastError();
 }

@@ -5,10 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from semanticsegmentationactivelearning_amd import _lib
 L = _lib.lib()
-n, h, w = 8, 256, 512
+n, h, w = (int(sys.argv[1]) if len(sys.argv) > 1 else 8), 256, 512
 x = torch.randn(n, h, w, 64, device="cuda"); y = torch.empty_like(x); y2 = torch.empty_like(x)
 names = ["linear", "tile 8x32 frag", "tile 8x32 coalesced", "tile 8x32 frag+halo", "tile 8x32 coalesced+halo",
-         "tile 4x64 frag", "tile 2x128 frag", "tile 1x256 frag", "tile 16x16 frag"]
+         "tile 4x64 frag", "tile 2x128 frag", "tile 1x256 frag", "tile 16x16 frag", "tile 8x32 frag, group by group"]
 def run(mode, spin, reps=20, out=y):
     _lib.check(L.ssal_debug_copy_probe(mode, _lib.dev_ptr(x), _lib.dev_ptr(out), n, h, w, spin, _lib.stream_ptr()))
     torch.cuda.synchronize()
@@ -18,6 +18,7 @@ def run(mode, spin, reps=20, out=y):
         _lib.check(L.ssal_debug_copy_probe(mode, _lib.dev_ptr(x), _lib.dev_ptr(out), n, h, w, spin, _lib.stream_ptr()))
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
+print("tensor [%d,%d,%d,64] fp32 = %.0f MB in + the same out" % (n, h, w, x.numel() * 4 / 1e6))
 for mode in range(len(names)):
     y.zero_()
     us = run(mode, 0)

@@ -26,6 +26,7 @@
 #include "ssal_bottleneck_args.h"
 #include "ssal_prof.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace ssal {
 
@@ -656,146 +657,264 @@ __global__ __launch_bounds__(256, 2) void k_downsample_mfma(DownArgs a)
 
 constexpr int CUP = 64;  // output channels of the upsample block
 
+// Structure (the k_bottleneck16 recipe): the tile's CENTRE pixels are projected with the (wave, M-tile,
+// lane) mapping phase B uses, and the SAME swapped activation fragment feeds three accumulators per
+// k-pair step -- the projection D[pixel][co] and the two N-tiles of the 1x1 residual conv, evaluated as
+// D[co][pixel] -- so the block input is read once and the residual waits in registers in exactly the
+// layout of the (flipped) expansion output: lane = pixel, 4 consecutive channels per register group,
+// hence packed window codes (one 32-bit load per group) and float4 stores.  Kernel fragments stream from
+// L1 through rolling windows; the transposed conv is pipelined one slot ahead like conv_tile_q.
 template <int TW>
 __global__ __launch_bounds__(256, 2) void k_upsample_mfma(UpArgs a)
 {
+    constexpr int TH = 8, HW2 = TW + 2;
+    constexpr int MPW = (TH * TW) / 32 / 4;  // centre M-tiles per wave: 2 (TW 32) or 1 (TW 16)
+    constexpr int RING = 2 * HW2 + 2 * TH;   // 84 / 52
+    constexpr int NRMT = (RING + 31) / 32;   // ring M-tiles: wave w < NRMT projects ring tile w
+    constexpr int QDUMP = PMAX - 1;          // spare P row for M-tile pixels beyond the ring
     __shared__ float P[PMAX * PSTR];
+    __shared__ float BNV[3 * CUP + 3 * 16];  // es | et | ra (64 each), then cs | ct | ca (16 each)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
-    constexpr int HW2 = TW + 2;
     int b = blockIdx.x;
     const int tx = b % a.tiles_x; b /= a.tiles_x;
     const int ty = b % a.tiles_y; b /= a.tiles_y;
     const int n = b;
-    const int TH = a.TH;
     const int ty0 = ty * TH, tx0 = tx * TW;
     const float *ximg = a.x + (long)n * a.H * a.W * C;
     const uint8_t *cimg = a.code + (long)n * a.H * a.W * CUP;
     float *yimg = a.y + (long)n * 4 * a.H * a.W * CUP;
 
-    proj_to_lds<TW, 1>(a, ximg, P, TH, ty0, tx0, 0, 0, a.H, a.W, wave, j, h);
+    if (threadIdx.x < 3 * CUP / 4) {
+        const int arr = threadIdx.x / (CUP / 4), k4 = threadIdx.x % (CUP / 4);
+        const float *src = arr == 0 ? a.es : arr == 1 ? a.et : a.ra;
+        reinterpret_cast<float4 *>(BNV)[threadIdx.x] = reinterpret_cast<const float4 *>(src)[k4];
+    } else if (threadIdx.x < 3 * CUP / 4 + 12) {
+        const int q = threadIdx.x - 3 * CUP / 4, arr = q / 4, k4 = q % 4;
+        const float *src = arr == 0 ? a.cs : arr == 1 ? a.ct : a.ca;
+        reinterpret_cast<float4 *>(BNV + 3 * CUP)[q] = reinterpret_cast<const float4 *>(src)[k4];
+    }
+
+    // ---- phase A -------------------------------------------------------------------------------------
+    constexpr int WIN = 4;
+    const rsrc_t wprs = make_rsrc(a.wp, C * F * 4), wrrs = make_rsrc(a.wr, C * CUP * 4);
+    const unsigned wplo = (unsigned)lane * 4u;            // Wp fragment s of lane l = Wp[64 s + l]
+    const unsigned wrlo = (unsigned)(h * CUP + j) * 4u;   // Wr[2s + h][nt*32 + j] = + s*512 + nt*128 bytes
+    const float bs = a.ps[j], bt = a.pt[j], ba = a.pa[j];
+    auto q_ring = [&](int u) {  // halo'd-tile index of ring pixel u (branch-free)
+        const int k = u - 2 * HW2;
+        const int side = (1 + (k >> 1)) * HW2 + ((k & 1) ? HW2 - 1 : 0);
+        const int q = u < HW2 ? u : (u < 2 * HW2 ? (TH + 1) * HW2 + (u - HW2) : side);
+        return u < RING ? q : QDUMP;
+    };
+    // one M-tile; RES (compile time): also accumulate the 1x1 residual conv of the same pixels
+    auto project = [&](const float *xp, unsigned vmask, auto qf, auto RES, f32x16 &res0, f32x16 &res1) {
+        constexpr bool with_res = decltype(RES)::value;
+        float4 X[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) X[u] = *reinterpret_cast<const float4 *>(xp + (2 * u + h) * 4);
+        f32x16 acc = {0};
+        float pa_[WIN], pb_[WIN], r0a[WIN], r0b[WIN], r1a[WIN], r1b[WIN];
+        auto fetch_w = [&](int s0, float (&wp_)[WIN], float (&w0)[WIN], float (&w1)[WIN]) {
+#pragma unroll
+            for (int s = 0; s < WIN; ++s) {
+                wp_[s] = bload(wprs, wplo, (s0 + s) * 256);
+                if (with_res) {
+                    w0[s] = bload(wrrs, wrlo, (s0 + s) * 512);
+                    w1[s] = bload(wrrs, wrlo, (s0 + s) * 512 + 128);
+                }
+            }
+        };
+        auto steps = [&](int s0, const float (&wp_)[WIN], const float (&w0)[WIN], const float (&w1)[WIN]) {
+#pragma unroll
+            for (int v = 0; v < WIN / 4; ++v) {
+                const int u = s0 / 4 + v;
+                float a0 = X[u].x, a1 = X[u].y, a2 = X[u].z, a3 = X[u].w;
+                swap32(a0, a1);  // a0 = ch(8u+0 | 8u+1), a1 = ch(8u+4 | 8u+5)
+                swap32(a2, a3);  // a2 = ch(8u+2 | 8u+3), a3 = ch(8u+6 | 8u+7)
+                const float xs[4] = {a0, a2, a1, a3};  // ascending k-pair order
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc = mfma32(xs[q], wp_[4 * v + q], acc);
+                    if (with_res) {
+                        res0 = mfma32(w0[4 * v + q], xs[q], res0);
+                        res1 = mfma32(w1[4 * v + q], xs[q], res1);
+                    }
+                }
+            }
+        };
+        fetch_w(0, pa_, r0a, r1a);
+#pragma unroll
+        for (int s0 = 0; s0 < 64; s0 += 2 * WIN) {
+            fetch_w(s0 + WIN, pb_, r0b, r1b);
+            __builtin_amdgcn_sched_barrier(0);
+            steps(s0, pa_, r0a, r1a);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s0 + 2 * WIN < 64) fetch_w(s0 + 2 * WIN, pa_, r0a, r1a);
+            __builtin_amdgcn_sched_barrier(0);
+            steps(s0 + WIN, pb_, r0b, r1b);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {  // rows = pixels (registers), cols = co (lanes)
+            const int ri = (i & 3) + 8 * (i >> 2) + 4 * h;
+            const bool ok = (vmask >> ri) & 1u;
+            P[qf(ri) * PSTR + j] = ok ? prelu1(fmaf(acc[i], bs, bt), ba) : 0.0f;  // exact zero outside the image
+        }
+    };
+
+    f32x16 res[MPW][2];    // residual 1x1 conv of the lane's centre pixel: reg 4g + c = channel nt*32 + 8g + 4h + c
+    unsigned codes[MPW][8];  // window codes of channels nt*32 + 8g + 4h .. +3 (index 4 nt + g), one byte each
+    long ipixk[MPW];         // input pixel index of the lane's centre pixel, -1 outside the image
+    if (wave < NRMT) {       // wave-uniform: this wave's ring tile
+        const int u = wave * 32 + j;
+        const int q = q_ring(u);
+        const int pr = ty0 - 1 + q / HW2, pc = tx0 - 1 + q % HW2;
+        const bool rvalid = (u < RING) && pr >= 0 && pr < a.H && pc >= 0 && pc < a.W;
+        const float *xp = rvalid ? ximg + ((long)pr * a.W + pc) * C : ximg;
+        f32x16 d0 = {0}, d1 = {0};
+        project(xp, (unsigned)__ballot(rvalid), [&](int ri) { return q_ring(wave * 32 + ri); }, std::false_type(), d0, d1);
+    }
+#pragma unroll
+    for (int k = 0; k < MPW; ++k) {
+        const int mt = wave + 4 * k;
+        const int tt = mt * 32 + j;
+        const int iy = ty0 + tt / TW, ix = tx0 + tt % TW;
+        const bool valid = iy < a.H && ix < a.W;
+        ipixk[k] = valid ? (long)iy * a.W + ix : -1;
+        const float *xp = valid ? ximg + ipixk[k] * C : ximg;
+        const uint8_t *cp = cimg + (valid ? ipixk[k] : 0) * CUP + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) codes[k][q] = *reinterpret_cast<const unsigned *>(cp + 8 * q);  // nt*32 + 8g = 8 (4nt + g)
+        res[k][0] = (f32x16){0};
+        res[k][1] = (f32x16){0};
+        project(xp, (unsigned)__ballot(valid),
+                [&](int ri) { const int t2 = mt * 32 + ri; return (t2 / TW + 1) * HW2 + (t2 % TW) + 1; },
+                std::true_type(), res[k][0], res[k][1]);
+    }
+    // expansion kernel (16 -> 64) as A operand of the flipped expansion: lane (r = j, k = h)
+    float wef[2][8];
+    {
+        const rsrc_t wers = make_rsrc(a.we, 16 * CUP * 4);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int s = 0; s < 8; ++s) wef[nt][s] = bload(wers, wrlo, s * 512 + nt * 128);  // We[2s + h][nt*32 + j]
+    }
     __syncthreads();
 
-    const int nmt = (TH * TW) / 32;
-    for (int mt = wave; mt < nmt; mt += 4) {
+    // ---- phase B: transposed conv (2 stacked accumulators) -> expansion per parity class -> unpool-gated
+    // residual -> float4 stores ----------------------------------------------------------------------------
+    const rsrc_t wsrs = make_rsrc(a.ws, 6 * F * 32 * 4);
+    const float *bnl = BNV + 4 * h;
+#pragma unroll
+    for (int k = 0; k < MPW; ++k) {
+        const int mt = wave + 4 * k;
         const int t = mt * 32 + j;
         const int r = t / TW, c = t - r * TW;
-        const bool lane_ok = (ty0 + r < a.H) && (tx0 + c < a.W);
-
-        // ---- residual branch: D[pixel][co] = X[pixel][ci] * Wr[ci][co], two N-tiles of 32 --------
-        f32x16 res0 = {0}, res1 = {0};
-        {
-            const float *xp = lane_ok ? ximg + ((long)(ty0 + r) * a.W + (tx0 + c)) * C : ximg;
-#pragma unroll 1
-            for (int kc = 0; kc < 4; ++kc) {
-                float4 v[4];
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    v[m] = *reinterpret_cast<const float4 *>(xp + kc * 32 + (2 * m + h) * 4);
-                float w0[16], w1[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    w0[k] = a.wr[(kc * 32 + 2 * k + h) * CUP + j];
-                    w1[k] = a.wr[(kc * 32 + 2 * k + h) * CUP + 32 + j];
-                }
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    float a0 = v[m].x, a1 = v[m].y, a2 = v[m].z, a3 = v[m].w;
-                    swap32(a0, a1);
-                    swap32(a2, a3);
-                    res0 = mfma32(a0, w0[4 * m + 0], res0); res1 = mfma32(a0, w1[4 * m + 0], res1);
-                    res0 = mfma32(a2, w0[4 * m + 1], res0); res1 = mfma32(a2, w1[4 * m + 1], res1);
-                    res0 = mfma32(a1, w0[4 * m + 2], res0); res1 = mfma32(a1, w1[4 * m + 2], res1);
-                    res0 = mfma32(a3, w0[4 * m + 3], res0); res1 = mfma32(a3, w1[4 * m + 3], res1);
-                }
-            }
-        }
-
-        // ---- transposed conv: two stacked accumulators ------------------------------------------
         f32x16 accA = {0}, accB = {0};
-#pragma unroll 1
-        for (int slot = 0; slot < 4; ++slot) {  // P(i,j), P(i,j-1), P(i-1,j), P(i-1,j-1)
-            const int dr = 1 - (slot >> 1), dc = 1 - (slot & 1);
-            const float *pq = P + ((r + dr) * HW2 + (c + dc)) * PSTR + 2 * h;
-            const float *wt = a.ws + (slot * F + h) * 32 + j;
+        {
+            float wA[16], wB[16];
+            float2 pA[8], pB[8];
+            auto load_slot = [&](int slot, float (&w)[16], float2 (&pv)[8]) {
+                const int dr = slot < 4 ? 1 - (slot >> 1) : 1, dc = 1 - (slot & 1);
 #pragma unroll
-            for (int sq = 0; sq < 8; ++sq) {
-                float2 pv = *reinterpret_cast<const float2 *>(pq + 4 * sq);
-                float b0 = pv.x, b1 = pv.y;
-                swap32(b0, b1);
-                accA = mfma32(wt[(4 * sq) * 32], b0, accA);
-                accA = mfma32(wt[(4 * sq + 2) * 32], b1, accA);
-            }
-        }
-#pragma unroll 1
-        for (int slot = 4; slot < 6; ++slot) {  // P(i,j), P(i,j-1)
-            const int dc = 1 - (slot & 1);
-            const float *pq = P + ((r + 1) * HW2 + (c + dc)) * PSTR + 2 * h;
-            const float *wt = a.ws + (slot * F + h) * 32 + j;
+                for (int q = 0; q < 16; ++q) w[q] = bload(wsrs, wplo, (slot * 16 + q) * 256);  // ws[slot][2q + h][j]
+                const float *pq = P + ((r + dr) * HW2 + (c + dc)) * PSTR + 2 * h;
 #pragma unroll
-            for (int sq = 0; sq < 8; ++sq) {
-                float2 pv = *reinterpret_cast<const float2 *>(pq + 4 * sq);
-                float b0 = pv.x, b1 = pv.y;
-                swap32(b0, b1);
-                accB = mfma32(wt[(4 * sq) * 32], b0, accB);
-                accB = mfma32(wt[(4 * sq + 2) * 32], b1, accB);
-            }
+                for (int sq = 0; sq < 8; ++sq) pv[sq] = *reinterpret_cast<const float2 *>(pq + 4 * sq);
+            };
+            auto run_slot = [&](f32x16 &acc, const float (&w)[16], const float2 (&pv)[8]) {
+#pragma unroll
+                for (int sq = 0; sq < 8; ++sq) {
+                    float b0 = pv[sq].x, b1 = pv[sq].y;
+                    swap32(b0, b1);
+                    acc = mfma32(w[2 * sq], b0, acc);
+                    acc = mfma32(w[2 * sq + 1], b1, acc);
+                }
+            };
+            // slots 0..3 = P(i,j), P(i,j-1), P(i-1,j), P(i-1,j-1) -> [ee|eo];  4, 5 = P(i,j), P(i,j-1) -> [oe|oo]
+            load_slot(0, wA, pA);
+            load_slot(1, wB, pB);
+            __builtin_amdgcn_sched_barrier(0);
+            run_slot(accA, wA, pA);
+            __builtin_amdgcn_sched_barrier(0);
+            load_slot(2, wA, pA);
+            __builtin_amdgcn_sched_barrier(0);
+            run_slot(accA, wB, pB);
+            __builtin_amdgcn_sched_barrier(0);
+            load_slot(3, wB, pB);
+            __builtin_amdgcn_sched_barrier(0);
+            run_slot(accA, wA, pA);
+            __builtin_amdgcn_sched_barrier(0);
+            load_slot(4, wA, pA);
+            __builtin_amdgcn_sched_barrier(0);
+            run_slot(accA, wB, pB);
+            __builtin_amdgcn_sched_barrier(0);
+            load_slot(5, wB, pB);
+            __builtin_amdgcn_sched_barrier(0);
+            run_slot(accB, wA, pA);
+            __builtin_amdgcn_sched_barrier(0);
+            run_slot(accB, wB, pB);
         }
         // BN + PReLU; reg i: class = i >> 3, channel = (i&3) + 8*((i>>2)&1) + 4h
         float qa[16], qb[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int co = (i & 3) + 8 * ((i >> 2) & 1) + 4 * h;
-            const float sc = a.cs[co], sh = a.ct[co], al = a.ca[co];
-            qa[i] = prelu1(fmaf(accA[i], sc, sh), al);
-            qb[i] = prelu1(fmaf(accB[i], sc, sh), al);
+        for (int gq = 0; gq < 4; ++gq) {  // register group gq: channels 8*(gq&1) + 4h .. +3
+            const float4 sc = *reinterpret_cast<const float4 *>(bnl + 3 * CUP + 8 * (gq & 1));
+            const float4 sh = *reinterpret_cast<const float4 *>(bnl + 3 * CUP + 16 + 8 * (gq & 1));
+            const float4 al = *reinterpret_cast<const float4 *>(bnl + 3 * CUP + 32 + 8 * (gq & 1));
+            const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w}, alv[4] = {al.x, al.y, al.z, al.w};
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                qa[4 * gq + cc] = prelu1(fmaf(accA[4 * gq + cc], scv[cc], shv[cc]), alv[cc]);
+                qb[4 * gq + cc] = prelu1(fmaf(accB[4 * gq + cc], scv[cc], shv[cc]), alv[cc]);
+            }
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             swap32(qa[2 * u], qa[2 * u + 1]);
             swap32(qb[2 * u], qb[2 * u + 1]);
         }
-
-        // ---- expansion (16 -> 64) per parity class + BN + gather-unpool residual + PReLU ----------
-        int ooff[16], coff[16];
-        unsigned okmask = 0;
+        // expansion per (parity class, N-tile): D[co][pixel]; the chain of combination m+1 is issued
+        // interleaved with the epilogue of combination m
+        const bool ok = ipixk[k] >= 0;
+        const int iy = ty0 + r, ix = tx0 + c;
+        float *yq = yimg + (ok ? ((long)(2 * iy) * (2 * a.W) + 2 * ix) * CUP : 0) + 4 * h;
+        auto chain = [&](int m, f32x16 e) {  // m = cls * 2 + nt
+            const int cls = m >> 1, nt = m & 1;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int ti = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            const int rr = ti / TW, cc = ti - rr * TW;
-            const int iy = ty0 + rr, ix = tx0 + cc;
-            const bool ok = (iy < a.H) && (ix < a.W);
-            okmask |= ok ? (1u << i) : 0u;
-            coff[i] = ok ? (iy * a.W + ix) * CUP : 0;
-            ooff[i] = ok ? ((2 * iy) * (2 * a.W) + 2 * ix) * CUP : 0;
-        }
-#pragma unroll 1
-        for (int nt = 0; nt < 2; ++nt) {
-            const int co = nt * 32 + j;
-            float wef[8];
-#pragma unroll
-            for (int s = 0; s < 8; ++s) wef[s] = a.we[(2 * s + h) * CUP + co];
-            int cd[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) cd[i] = cimg[coff[i] + co];
-            const float s1 = a.es[co], t1 = a.et[co], al = a.ra[co];
-#pragma unroll
-            for (int cls = 0; cls < 4; ++cls) {  // ee, eo, oe, oo  (== window code dy*2+dx)
-                f32x16 e = {0};
-#pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    const float av = (cls < 2) ? qa[(cls & 1) * 8 + ord(s)] : qb[(cls & 1) * 8 + ord(s)];
-                    e = mfma32(av, wef[s], e);
-                }
-                const int shift = ((cls >> 1) * (2 * a.W) + (cls & 1)) * CUP;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float rs = nt == 0 ? res0[i] : res1[i];
-                    const float rsd = (cd[i] == cls) ? rs : 0.0f;
-                    const float v = prelu1(fmaf(e[i], s1, t1) + rsd, al);
-                    if ((okmask >> i) & 1u) yimg[ooff[i] + shift + co] = v;
-                }
+            for (int s = 0; s < 8; ++s) {
+                const float qv = cls < 2 ? qa[(cls & 1) * 8 + ord(s)] : qb[(cls & 1) * 8 + ord(s)];
+                e = mfma32(wef[nt][s], qv, e);
             }
+            return e;
+        };
+        auto epilogue = [&](int m, const f32x16 &e) {
+            const int cls = m >> 1, nt = m & 1;
+            float *yp = yq + ((cls >> 1) * (2 * a.W) + (cls & 1)) * CUP + nt * 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 s4 = *reinterpret_cast<const float4 *>(bnl + nt * 32 + 8 * g);
+                const float4 t4 = *reinterpret_cast<const float4 *>(bnl + CUP + nt * 32 + 8 * g);
+                const float4 a4 = *reinterpret_cast<const float4 *>(bnl + 2 * CUP + nt * 32 + 8 * g);
+                const unsigned cd = codes[k][4 * nt + g];
+                const f32x16 &rs = res[k][nt];
+                float4 o;  // unpool_2d as a gather: the residual lands on the output parity its window code names
+                o.x = prelu1(fmaf(e[4 * g + 0], s4.x, t4.x) + (((cd >> 0) & 0xFFu) == (unsigned)cls ? rs[4 * g + 0] : 0.0f), a4.x);
+                o.y = prelu1(fmaf(e[4 * g + 1], s4.y, t4.y) + (((cd >> 8) & 0xFFu) == (unsigned)cls ? rs[4 * g + 1] : 0.0f), a4.y);
+                o.z = prelu1(fmaf(e[4 * g + 2], s4.z, t4.z) + (((cd >> 16) & 0xFFu) == (unsigned)cls ? rs[4 * g + 2] : 0.0f), a4.z);
+                o.w = prelu1(fmaf(e[4 * g + 3], s4.w, t4.w) + (((cd >> 24) & 0xFFu) == (unsigned)cls ? rs[4 * g + 3] : 0.0f), a4.w);
+                if (ok) *reinterpret_cast<float4 *>(yp + 8 * g) = o;
+            }
+        };
+        f32x16 e0 = chain(0, (f32x16){0}), e1;
+#pragma unroll
+        for (int m = 0; m < 8; m += 2) {
+            e1 = chain(m + 1, (f32x16){0});
+            epilogue(m, e0);
+            if (m + 2 < 8) e0 = chain(m + 2, (f32x16){0});
+            epilogue(m + 1, e1);
         }
     }
 }

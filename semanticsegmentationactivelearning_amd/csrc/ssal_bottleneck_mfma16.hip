@@ -18,66 +18,6 @@ namespace ssal {
 
 constexpr int PMAX16 = 352;  // >= (8+2)*(32+2), multiple of 16
 
-// ---- phase A: 1x1 projection CC -> FF (+BN +PReLU) of the halo'd tile into LDS P[pixel][FF (+2)] ----
-template <int TW, int CC, int FF, typename Args>
-__device__ __forceinline__ void proj16_to_lds(const Args &a, const float *ximg, float *P, int TH,
-                                              int ty0, int tx0, int py, int px, int Hp, int Wp,
-                                              int wave, int i16, int g)
-{
-    constexpr int PS = FF + 2, HW2 = TW + 2, KP = CC / 4;
-    const int d = a.dil;
-    const int npix_halo = (TH + 2) * HW2;
-    const bool cval = i16 < FF;
-    const int ic = cval ? i16 : 0;
-    float wpr[KP];
-#pragma unroll
-    for (int s = 0; s < KP; ++s) {
-        const float w = a.wp[(4 * s + g) * FF + ic];
-        wpr[s] = cval ? w : 0.0f;
-    }
-    const float bs = a.ps[ic], bt = a.pt[ic], ba = a.pa[ic];
-    const int nmt = (npix_halo + 15) / 16;
-    // the activation fragments of M-tile mt + 4 are requested before M-tile mt is projected
-    auto frags = [&](int mt, float4 (&v)[CC / 16], bool &valid) {
-        const int q = mt * 16 + i16;
-        const int hr = q / HW2, hc = q - hr * HW2;
-        const int pr = ty0 - 1 + hr, pc = tx0 - 1 + hc;
-        valid = (q < npix_halo) && (pr >= 0) && (pr < Hp) && (pc >= 0) && (pc < Wp);
-        const float *xp = valid ? ximg + ((long)(py + pr * d) * a.W + (px + pc * d)) * CC : ximg;
-#pragma unroll
-        for (int m = 0; m < CC / 16; ++m)  // quarter g takes the g-th float4 of every 16 channels
-            v[m] = *reinterpret_cast<const float4 *>(xp + 16 * m + 4 * g);
-    };
-    float4 v[CC / 16], vn[CC / 16];
-    bool valid = false, validn = false;
-    if (wave < nmt) frags(wave, v, valid);
-    for (int mt = wave; mt < nmt; mt += 4) {
-        if (mt + 4 < nmt) frags(mt + 4, vn, validn);
-        const unsigned vmask = (unsigned)(__ballot(valid) & 0xFFFFull);
-        f32x4 acc = {0};
-#pragma unroll
-        for (int m = 0; m < CC / 16; ++m) {
-            float r0 = v[m].x, r1 = v[m].y, r2 = v[m].z, r3 = v[m].w;
-            transpose4(r0, r1, r2, r3);  // reg r of quarter g: channel 16m + 4r + g
-            acc = mfma16(r0, wpr[4 * m + 0], acc);
-            acc = mfma16(r1, wpr[4 * m + 1], acc);
-            acc = mfma16(r2, wpr[4 * m + 2], acc);
-            acc = mfma16(r3, wpr[4 * m + 3], acc);
-        }
-        if (cval) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int pix = 4 * g + r;
-                const bool ok = (vmask >> pix) & 1u;
-                P[(mt * 16 + pix) * PS + i16] = ok ? prelu1(fmaf(acc[r], bs, bt), ba) : 0.0f;
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < CC / 16; ++m) v[m] = vn[m];
-        valid = validn;
-    }
-}
-
 // ---- weights of the 3x3 conv FF -> FF as A-operand fragments, loaded ONCE per wave (they are
 // identical for every M-tile): wcr[tap*KF + s] = Wc[tap][ci = 4s + g][co = i16] (0 beyond FF) ------
 template <int FF, typename Args>
@@ -328,10 +268,19 @@ __global__ __launch_bounds__(256, 3) void k_bottleneck16(BnkArgs a)
 // =================================================================================================
 // downsample bottleneck 16 -> 64, width 8 (Bottleneck1_0; enet_modules.py:868-938)
 // =================================================================================================
+// The tile's centre output pixels are projected with the (wave, M-tile, lane) mapping phase B uses: the four
+// 2x2-patch fragments the projection loads (channels 4g..4g+3 of each tap) are the pooling window of the
+// residual, so the first-max pooling and its packed window codes are evaluated right there (codes stored at
+// once, one pooled float4 per M-tile kept) and the block input is read once.  All patch loads of a wave
+// (centre + its share of the halo ring) are requested up front.
 template <int TW>
-__global__ __launch_bounds__(256, 4) void k_downsample16(DownArgs a)
+__global__ __launch_bounds__(256, 3) void k_downsample16(DownArgs a)
 {
     constexpr int CI = 16, FF = 8, CO = 64, PS = FF + 2, HW2 = TW + 2;
+    constexpr int TH = 8;                      // tile rows (launcher guarantees a.TH == 8)
+    constexpr int MPW = (TH * TW) / 16 / 4;    // centre M-tiles per wave: 4 (TW 32) or 2 (TW 16)
+    constexpr int RING = 2 * HW2 + 2 * TH;     // halo ring pixels: 84 or 52
+    constexpr int RM = (RING + 63) / 64;       // ring M-tiles per wave (upper bound)
     __shared__ float P[PMAX16 * PS];
     __shared__ float BNV[3 * CO];  // es | et | ra, read in phase B through LDS
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -346,7 +295,6 @@ __global__ __launch_bounds__(256, 4) void k_downsample16(DownArgs a)
     const int tx = b % a.tiles_x; b /= a.tiles_x;
     const int ty = b % a.tiles_y; b /= a.tiles_y;
     const int n = b;
-    const int TH = a.TH;
     const int ty0 = ty * TH, tx0 = tx * TW;
     const float *ximg = a.x + (long)n * a.H * a.W * CI;
     float *yimg = a.y + (long)n * Ho * Wo * CO;
@@ -354,61 +302,112 @@ __global__ __launch_bounds__(256, 4) void k_downsample16(DownArgs a)
     const bool cval = i16 < FF;
     const int ic = cval ? i16 : 0;
 
-    // ---- phase A: 2x2/s2 projection (K = 4 taps x 16 ci) of the halo'd output tile -> LDS ----------
-    {
-        float wpr[16];
+    // ---- phase A: 2x2/s2 projection (K = 4 taps x 16 ci) of centre + ring -> LDS --------------------
+    float wpr[16];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {  // step s = 4*tap + s': ci = 4s' + g of tap (dy,dx)
-            const float w = a.wp[((s >> 2) * CI + 4 * (s & 3) + g) * FF + ic];
-            wpr[s] = cval ? w : 0.0f;
+    for (int s = 0; s < 16; ++s) {  // step s = 4*tap + s': ci = 4s' + g of tap (dy,dx)
+        const float w = a.wp[((s >> 2) * CI + 4 * (s & 3) + g) * FF + ic];
+        wpr[s] = cval ? w : 0.0f;
+    }
+    const float bs = a.ps[ic], bt = a.pt[ic], ba = a.pa[ic];
+    auto q_center = [&](int t) { return (t / TW + 1) * HW2 + (t % TW) + 1; };
+    auto q_ring = [&](int u) {
+        if (u < HW2) return u;
+        if (u < 2 * HW2) return (TH + 1) * HW2 + (u - HW2);
+        const int k = u - 2 * HW2;
+        return (1 + (k >> 1)) * HW2 + ((k & 1) ? HW2 - 1 : 0);
+    };
+    auto load_patch = [&](const float *xp, float4 (&v)[4]) {  // taps in (dy,dx) order = (kh,kw) order of the oracle
+#pragma unroll
+        for (int tap = 0; tap < 4; ++tap)
+            v[tap] = *reinterpret_cast<const float4 *>(xp + ((tap >> 1) * a.W + (tap & 1)) * CI + 4 * g);
+    };
+    auto project = [&](const float4 (&v)[4], unsigned vmask, const int (&qrow)[4]) {
+        f32x4 acc = {0};
+#pragma unroll
+        for (int tap = 0; tap < 4; ++tap) {
+            float r0 = v[tap].x, r1 = v[tap].y, r2 = v[tap].z, r3 = v[tap].w;
+            transpose4(r0, r1, r2, r3);
+            acc = mfma16(r0, wpr[4 * tap + 0], acc);
+            acc = mfma16(r1, wpr[4 * tap + 1], acc);
+            acc = mfma16(r2, wpr[4 * tap + 2], acc);
+            acc = mfma16(r3, wpr[4 * tap + 3], acc);
         }
-        const float bs = a.ps[ic], bt = a.pt[ic], ba = a.pa[ic];
-        const int npix_halo = (TH + 2) * HW2;
-        const int nmt = (npix_halo + 15) / 16;
-        // the 2x2 patch fragments of M-tile mt + 4 are requested before M-tile mt is projected
-        auto patch = [&](int mt, float4 (&v)[4], bool &valid) {
-            const int q = mt * 16 + i16;
-            const int hr = q / HW2, hc = q - hr * HW2;
-            const int pr = ty0 - 1 + hr, pc = tx0 - 1 + hc;
-            valid = (q < npix_halo) && (pr >= 0) && (pr < Ho) && (pc >= 0) && (pc < Wo);
-            const float *xp = valid ? ximg + ((long)(2 * pr) * a.W + 2 * pc) * CI : ximg;
+        if (cval) {
 #pragma unroll
-            for (int tap = 0; tap < 4; ++tap)
-                v[tap] = *reinterpret_cast<const float4 *>(xp + ((tap >> 1) * a.W + (tap & 1)) * CI + 4 * g);
-        };
-        float4 v[4], vn[4];
-        bool valid = false, validn = false;
-        if (wave < nmt) patch(wave, v, valid);
-        for (int mt = wave; mt < nmt; mt += 4) {
-            if (mt + 4 < nmt) patch(mt + 4, vn, validn);
-            const unsigned vmask = (unsigned)(__ballot(valid) & 0xFFFFull);
-            f32x4 acc = {0};
-#pragma unroll
-            for (int tap = 0; tap < 4; ++tap) {
-                float r0 = v[tap].x, r1 = v[tap].y, r2 = v[tap].z, r3 = v[tap].w;
-                transpose4(r0, r1, r2, r3);
-                acc = mfma16(r0, wpr[4 * tap + 0], acc);
-                acc = mfma16(r1, wpr[4 * tap + 1], acc);
-                acc = mfma16(r2, wpr[4 * tap + 2], acc);
-                acc = mfma16(r3, wpr[4 * tap + 3], acc);
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = (vmask >> (4 * g + r)) & 1u;
+                if (qrow[r] >= 0) P[qrow[r] * PS + i16] = ok ? prelu1(fmaf(acc[r], bs, bt), ba) : 0.0f;
             }
-            if (cval) {
+        }
+    };
+
+    float4 vk[MPW][4], vr[RM][4];
+    long opixk[MPW];  // output pixel index of the lane's centre pixel, -1 outside the image
+    bool rvalid[RM];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int pix = 4 * g + r;
-                    const bool ok = (vmask >> pix) & 1u;
-                    P[(mt * 16 + pix) * PS + i16] = ok ? prelu1(fmaf(acc[r], bs, bt), ba) : 0.0f;
-                }
+    for (int k = 0; k < MPW; ++k) {
+        const int t = (wave + 4 * k) * 16 + i16;
+        const int oy = ty0 + t / TW, ox = tx0 + t % TW;
+        const bool valid = (oy < Ho) && (ox < Wo);
+        opixk[k] = valid ? (long)oy * Wo + ox : -1;
+        load_patch(valid ? ximg + ((long)(2 * oy) * a.W + 2 * ox) * CI : ximg, vk[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < RM; ++k) {
+        const int u = (wave + 4 * k) * 16 + i16;
+        const int q = u < RING ? q_ring(u) : 0;
+        const int pr = ty0 - 1 + q / HW2, pc = tx0 - 1 + q % HW2;
+        rvalid[k] = (u < RING) && (pr >= 0) && (pr < Ho) && (pc >= 0) && (pc < Wo);
+        load_patch(rvalid[k] ? ximg + ((long)(2 * pr) * a.W + 2 * pc) * CI : ximg, vr[k]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    float4 pooled[MPW];  // max-pooled input, channels 4g..4g+3 of the lane's centre pixel (N-tile 0 residual)
+#pragma unroll
+    for (int k = 0; k < MPW; ++k) {
+        const int mt = wave + 4 * k;
+        const unsigned vmask = (unsigned)(__ballot(opixk[k] >= 0) & 0xFFFFull);
+        int qrow[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) qrow[r] = q_center(mt * 16 + 4 * g + r);
+        project(vk[k], vmask, qrow);
+        // 2x2 window, strict '>' scan in (dy,dx) order: the first maximum wins (TF's rule)
+        const float c00[4] = {vk[k][0].x, vk[k][0].y, vk[k][0].z, vk[k][0].w};
+        const float c01[4] = {vk[k][1].x, vk[k][1].y, vk[k][1].z, vk[k][1].w};
+        const float c10[4] = {vk[k][2].x, vk[k][2].y, vk[k][2].z, vk[k][2].w};
+        const float c11[4] = {vk[k][3].x, vk[k][3].y, vk[k][3].z, vk[k][3].w};
+        float best[4];
+        unsigned packed = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float bv = c00[r];
+            unsigned cd = 0;
+            if (c01[r] > bv) { bv = c01[r]; cd = 1; }
+            if (c10[r] > bv) { bv = c10[r]; cd = 2; }
+            if (c11[r] > bv) { bv = c11[r]; cd = 3; }
+            best[r] = bv;
+            packed |= cd << (8 * r);
+        }
+        pooled[k] = make_float4(best[0], best[1], best[2], best[3]);
+        if (opixk[k] >= 0) *reinterpret_cast<unsigned *>(cimg + opixk[k] * CI + 4 * g) = packed;  // channels 4g..4g+3
+    }
+#pragma unroll
+    for (int k = 0; k < RM; ++k) {  // halo ring
+        const int mtr = wave + 4 * k;
+        if (mtr * 16 < RING) {  // wave-uniform
+            const unsigned vmask = (unsigned)(__ballot(rvalid[k]) & 0xFFFFull);
+            int qrow[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ur = mtr * 16 + 4 * g + r;
+                qrow[r] = ur < RING ? q_ring(ur) : -1;
             }
-#pragma unroll
-            for (int tap = 0; tap < 4; ++tap) v[tap] = vn[tap];
-            valid = validn;
+            project(vr[k], vmask, qrow);
         }
     }
-    __syncthreads();
 
-    // ---- phase B: 3x3 conv (8 -> 8), expansion (8 -> 64) as D[co][pixel] (lane = pixel, 4 consecutive
-    // channels per lane -> float4 I/O), pooled residual + packed window codes ----------------------
+    // loop-invariant operands of phase B, requested before the barrier
     float wcr[9 * (FF / 4)];
     load_conv16_weights<FF>(a, i16, g, wcr);
     float cs[4], ct[4], ca[4];
@@ -419,52 +418,15 @@ __global__ __launch_bounds__(256, 4) void k_downsample16(DownArgs a)
         wer[nt * 2 + 0] = a.we[(0 + g) * CO + nt * 16 + i16];
         wer[nt * 2 + 1] = a.we[(4 + g) * CO + nt * 16 + i16];
     }
-    const int nmt_out = (TH * TW) / 16;
-    // pooling window of channels 4g..4g+3 (N-tile 0) of M-tile mt; requested one M-tile ahead, i.e. BEFORE
-    // the stores of the current M-tile (loads return in order: a load behind a store waits for its ack)
-    auto window = [&](int mt, float4 (&pv)[4], bool &ok, long &opix) {
-        const int t = mt * 16 + i16;
-        const int rr = t / TW, cc = t - rr * TW;
-        const int oy = ty0 + rr, ox = tx0 + cc;
-        ok = (oy < Ho) && (ox < Wo);
-        opix = ok ? (long)oy * Wo + ox : 0;
-        const float *w0 = ximg + (ok ? ((long)(2 * oy) * a.W + 2 * ox) * CI : 0) + 4 * g;
-        pv[0] = *reinterpret_cast<const float4 *>(w0);
-        pv[1] = *reinterpret_cast<const float4 *>(w0 + CI);
-        pv[2] = *reinterpret_cast<const float4 *>(w0 + (long)a.W * CI);
-        pv[3] = *reinterpret_cast<const float4 *>(w0 + (long)a.W * CI + CI);
-    };
-    float4 pv[4], pn[4];
-    bool ok = false, okn = false;
-    long opix = 0, opixn = 0;
-    if (wave < nmt_out) window(wave, pv, ok, opix);
-    for (int mt = wave; mt < nmt_out; mt += 4) {
-        if (mt + 4 < nmt_out) window(mt + 4, pn, okn, opixn);
-        const float4 v00 = pv[0], v01 = pv[1], v10 = pv[2], v11 = pv[3];  // first maximum wins
+    __syncthreads();
 
+    // ---- phase B: 3x3 conv (8 -> 8), expansion (8 -> 64) as D[co][pixel] (lane = pixel, 4 consecutive
+    // channels per lane -> float4 stores), + pooled residual on N-tile 0; no global load in this phase ----
+#pragma unroll
+    for (int k = 0; k < MPW; ++k) {
+        const int mt = wave + 4 * k;
         float q[4];
         conv16_tile_q<TW, FF>(P, wcr, cs, ct, ca, mt, i16, g, q);
-
-        float4 rx;
-        unsigned packed = 0;
-        {
-            const float c00[4] = {v00.x, v00.y, v00.z, v00.w}, c01[4] = {v01.x, v01.y, v01.z, v01.w};
-            const float c10[4] = {v10.x, v10.y, v10.z, v10.w}, c11[4] = {v11.x, v11.y, v11.z, v11.w};
-            float best[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float bv = c00[r];
-                unsigned cd = 0;
-                if (c01[r] > bv) { bv = c01[r]; cd = 1; }
-                if (c10[r] > bv) { bv = c10[r]; cd = 2; }
-                if (c11[r] > bv) { bv = c11[r]; cd = 3; }
-                best[r] = bv;
-                packed |= cd << (8 * r);
-            }
-            rx = make_float4(best[0], best[1], best[2], best[3]);
-        }
-        if (ok) *reinterpret_cast<unsigned *>(cimg + opix * CI + 4 * g) = packed;  // 4 codes, channels 4g..4g+3
-
 #pragma unroll
         for (int nt = 0; nt < CO / 16; ++nt) {
             f32x4 e = {0};
@@ -474,18 +436,14 @@ __global__ __launch_bounds__(256, 4) void k_downsample16(DownArgs a)
             const float4 s1 = *reinterpret_cast<const float4 *>(BNV + co);
             const float4 t1 = *reinterpret_cast<const float4 *>(BNV + CO + co);
             const float4 al = *reinterpret_cast<const float4 *>(BNV + 2 * CO + co);
-            const float4 rr4 = nt == 0 ? rx : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 rr4 = nt == 0 ? pooled[k] : make_float4(0.f, 0.f, 0.f, 0.f);  // channels >= 16: zero padding
             float4 o;
             o.x = prelu1(fmaf(e[0], s1.x, t1.x) + rr4.x, al.x);
             o.y = prelu1(fmaf(e[1], s1.y, t1.y) + rr4.y, al.y);
             o.z = prelu1(fmaf(e[2], s1.z, t1.z) + rr4.z, al.z);
             o.w = prelu1(fmaf(e[3], s1.w, t1.w) + rr4.w, al.w);
-            if (ok) *reinterpret_cast<float4 *>(yimg + opix * CO + co) = o;
+            if (opixk[k] >= 0) *reinterpret_cast<float4 *>(yimg + opixk[k] * CO + co) = o;
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) pv[k] = pn[k];
-        ok = okn;
-        opix = opixn;
     }
 }
 
@@ -494,10 +452,17 @@ __global__ __launch_bounds__(256, 4) void k_downsample16(DownArgs a)
 // conv 16 -> 8 with two output-parity classes stacked in the 16 MFMA rows ([ee|eo] and [oe|oo], see
 // ssal_bottleneck_mfma.hip), exp 8 -> 16, residual 1x1 conv 64 -> 16 + gather-unpool.
 // =================================================================================================
+// Centre pixels are projected with the (wave, M-tile, lane) mapping phase B uses and the same transposed
+// activation registers feed the 1x1 residual conv (64 -> 16, D[co][pixel]) in the same pass: the block input
+// is read once, the residual (4 registers per M-tile) and the packed window codes wait in registers.
 template <int TW>
 __global__ __launch_bounds__(256, 3) void k_upsample16(UpArgs a)
 {
-    constexpr int CI = 64, PF = 16, CF = 8, CO = 16, PS = PF + 2, HW2 = TW + 2;
+    constexpr int CI = 64, PF = 16, CF = 8, CO = 16, PS = PF + 2, HW2 = TW + 2, NT = CI / 16;
+    constexpr int TH = 8;                      // tile rows (launcher guarantees a.TH == 8)
+    constexpr int MPW = (TH * TW) / 16 / 4;    // centre M-tiles per wave: 4 (TW 32) or 2 (TW 16)
+    constexpr int RING = 2 * HW2 + 2 * TH;     // halo ring pixels: 84 or 52
+    constexpr int RM = (RING + 63) / 64;       // ring M-tiles per wave (upper bound)
     __shared__ float P[PMAX16 * PS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, g = lane >> 4;
@@ -505,78 +470,130 @@ __global__ __launch_bounds__(256, 3) void k_upsample16(UpArgs a)
     const int tx = b % a.tiles_x; b /= a.tiles_x;
     const int ty = b % a.tiles_y; b /= a.tiles_y;
     const int n = b;
-    const int TH = a.TH;
     const int ty0 = ty * TH, tx0 = tx * TW;
     const float *ximg = a.x + (long)n * a.H * a.W * CI;
     const uint8_t *cimg = a.code + (long)n * a.H * a.W * CO;
     float *yimg = a.y + (long)n * 4 * a.H * a.W * CO;
 
-    proj16_to_lds<TW, CI, PF>(a, ximg, P, TH, ty0, tx0, 0, 0, a.H, a.W, wave, i16, g);
-    __syncthreads();
-
-    // BN + PReLU constants of the transposed conv: reg r of quarter g holds channel 4*(g&1) + r
-    float cs[4], ct[4], ca[4];
+    // ---- phase A: projection 64 -> 16 (+ residual conv 64 -> 16 on the centre) ---------------------------
+    float wpr[CI / 4], wrr[CI / 4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int co = 4 * (g & 1) + r;
-        cs[r] = a.cs[co]; ct[r] = a.ct[co]; ca[r] = a.ca[co];
+    for (int s_ = 0; s_ < CI / 4; ++s_) {
+        wpr[s_] = a.wp[(4 * s_ + g) * PF + i16];  // B operand of the projection: Wp[ci = 4s + g][co = i16]
+        wrr[s_] = a.wr[(4 * s_ + g) * CO + i16];  // A operand of the residual conv: Wr^T[co = i16][ci = 4s + g]
     }
-    // exp (8 -> 16) and residual conv (64 -> 16) are evaluated as D[co][pixel]: lane = pixel, reg r =
-    // channel 4g + r, so codes, residual and output are one 4-byte / 16-byte access per lane
-    const float4 s1 = *reinterpret_cast<const float4 *>(a.es + 4 * g);
-    const float4 t1 = *reinterpret_cast<const float4 *>(a.et + 4 * g);
-    const float4 al = *reinterpret_cast<const float4 *>(a.ra + 4 * g);
-    const float we0 = a.we[(0 + g) * CO + i16], we1 = a.we[(4 + g) * CO + i16];  // A: row co = i16
-    float wrr[16];  // Wr^T as A operand: row = co (i16), k = ci = 4s + g
-#pragma unroll
-    for (int s_ = 0; s_ < 16; ++s_) wrr[s_] = a.wr[(4 * s_ + g) * CO + i16];
-
-    // stacked transposed-conv kernel as A operand, all 6 slots (identical for every M-tile)
-    float wsr[6 * 4];
-#pragma unroll
-    for (int slot = 0; slot < 6; ++slot)
-#pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_) wsr[slot * 4 + s_] = a.ws[(slot * PF + 4 * s_ + g) * 16 + i16];
-
-    const int nmt = (TH * TW) / 16;
-    // activation fragments (residual conv) and window codes of M-tile mt: requested one M-tile ahead, i.e.
-    // BEFORE the stores of the current M-tile (loads return in order: a load behind a store waits for its ack)
-    auto fetch = [&](int mt, float4 (&xv)[4], unsigned &codes, bool &ok, long &ipix) {
-        const int t = mt * 16 + i16;
-        const int r_ = t / TW, c_ = t - r_ * TW;
-        const int iy = ty0 + r_, ix = tx0 + c_;
-        ok = (iy < a.H) && (ix < a.W);
-        ipix = ok ? (long)iy * a.W + ix : 0;
-        const float *xp = ximg + ipix * CI;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) xv[m] = *reinterpret_cast<const float4 *>(xp + 16 * m + 4 * g);
-        codes = *reinterpret_cast<const unsigned *>(cimg + ipix * CO + 4 * g);
+    const float bs = a.ps[i16], bt = a.pt[i16], ba = a.pa[i16];
+    auto q_center = [&](int t) { return (t / TW + 1) * HW2 + (t % TW) + 1; };
+    auto q_ring = [&](int u) {
+        if (u < HW2) return u;
+        if (u < 2 * HW2) return (TH + 1) * HW2 + (u - HW2);
+        const int k = u - 2 * HW2;
+        return (1 + (k >> 1)) * HW2 + ((k & 1) ? HW2 - 1 : 0);
     };
-    float4 v[4], vn[4];
-    unsigned codes = 0, codesn = 0;
-    bool ok = false, okn = false;
-    long ipix = 0, ipixn = 0;
-    if (wave < nmt) fetch(wave, v, codes, ok, ipix);
-    for (int mt = wave; mt < nmt; mt += 4) {
-        if (mt + 4 < nmt) fetch(mt + 4, vn, codesn, okn, ipixn);
-        const int t = mt * 16 + i16;
-        const int r_ = t / TW, c_ = t - r_ * TW;
-        const int iy = ty0 + r_, ix = tx0 + c_;
-
-        // ---- residual branch: D[co][pixel] = Wr^T[co][ci] * X[ci][pixel]  (64 -> 16) -----------------
-        f32x4 res = {0};
-        {
+    auto load_frags = [&](const float *xp, float4 (&v)[NT]) {  // quarter g takes the g-th float4 of every 16 channels
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                float r0 = v[m].x, r1 = v[m].y, r2 = v[m].z, r3 = v[m].w;
-                transpose4(r0, r1, r2, r3);  // reg r of quarter g: channel 16m + 4r + g
+        for (int m = 0; m < NT; ++m) v[m] = *reinterpret_cast<const float4 *>(xp + 16 * m + 4 * g);
+    };
+    auto project = [&](const float4 (&v)[NT], unsigned vmask, const int (&qrow)[4], bool with_res, f32x4 &res) {
+        f32x4 acc = {0};
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+            float r0 = v[m].x, r1 = v[m].y, r2 = v[m].z, r3 = v[m].w;
+            transpose4(r0, r1, r2, r3);  // reg r of quarter g: channel 16m + 4r + g
+            acc = mfma16(r0, wpr[4 * m + 0], acc);
+            acc = mfma16(r1, wpr[4 * m + 1], acc);
+            acc = mfma16(r2, wpr[4 * m + 2], acc);
+            acc = mfma16(r3, wpr[4 * m + 3], acc);
+            if (with_res) {
                 res = mfma16(wrr[4 * m + 0], r0, res);
                 res = mfma16(wrr[4 * m + 1], r1, res);
                 res = mfma16(wrr[4 * m + 2], r2, res);
                 res = mfma16(wrr[4 * m + 3], r3, res);
             }
         }
-        // ---- transposed conv 16 -> 8: accA rows [ee|eo], accB rows [oe|oo] ---------------------------
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool ok = (vmask >> (4 * g + r)) & 1u;
+            if (qrow[r] >= 0) P[qrow[r] * PS + i16] = ok ? prelu1(fmaf(acc[r], bs, bt), ba) : 0.0f;
+        }
+    };
+
+    float4 vk[MPW][NT], vr[RM][NT];
+    unsigned codes[MPW];  // window codes of channels 4g..4g+3 of the lane's centre pixel
+    long ipixk[MPW];      // input pixel index of the lane's centre pixel, -1 outside the image
+    bool rvalid[RM];
+#pragma unroll
+    for (int k = 0; k < MPW; ++k) {
+        const int t = (wave + 4 * k) * 16 + i16;
+        const int iy = ty0 + t / TW, ix = tx0 + t % TW;
+        const bool valid = (iy < a.H) && (ix < a.W);
+        ipixk[k] = valid ? (long)iy * a.W + ix : -1;
+        load_frags(ximg + (valid ? ipixk[k] : 0) * CI, vk[k]);
+        codes[k] = *reinterpret_cast<const unsigned *>(cimg + (valid ? ipixk[k] : 0) * CO + 4 * g);
+    }
+#pragma unroll
+    for (int k = 0; k < RM; ++k) {
+        const int u = (wave + 4 * k) * 16 + i16;
+        const int q = u < RING ? q_ring(u) : 0;
+        const int pr = ty0 - 1 + q / HW2, pc = tx0 - 1 + q % HW2;
+        rvalid[k] = (u < RING) && (pr >= 0) && (pr < a.H) && (pc >= 0) && (pc < a.W);
+        load_frags(rvalid[k] ? ximg + ((long)pr * a.W + pc) * CI : ximg, vr[k]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    f32x4 resk[MPW];  // residual conv of the centre pixel: reg r = channel 4g + r
+#pragma unroll
+    for (int k = 0; k < MPW; ++k) {
+        const int mt = wave + 4 * k;
+        const unsigned vmask = (unsigned)(__ballot(ipixk[k] >= 0) & 0xFFFFull);
+        int qrow[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) qrow[r] = q_center(mt * 16 + 4 * g + r);
+        resk[k] = (f32x4){0};
+        project(vk[k], vmask, qrow, true, resk[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < RM; ++k) {  // halo ring
+        const int mtr = wave + 4 * k;
+        if (mtr * 16 < RING) {  // wave-uniform
+            const unsigned vmask = (unsigned)(__ballot(rvalid[k]) & 0xFFFFull);
+            int qrow[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ur = mtr * 16 + 4 * g + r;
+                qrow[r] = ur < RING ? q_ring(ur) : -1;
+            }
+            f32x4 dummy = {0};
+            project(vr[k], vmask, qrow, false, dummy);
+        }
+    }
+
+    // loop-invariant operands of phase B, requested before the barrier (no global load after it)
+    float cs[4], ct[4], ca[4];  // transposed conv BN + PReLU: reg r of quarter g holds channel 4*(g&1) + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = 4 * (g & 1) + r;
+        cs[r] = a.cs[co]; ct[r] = a.ct[co]; ca[r] = a.ca[co];
+    }
+    // exp (8 -> 16) is evaluated as D[co][pixel]: lane = pixel, reg r = channel 4g + r
+    const float4 s1 = *reinterpret_cast<const float4 *>(a.es + 4 * g);
+    const float4 t1 = *reinterpret_cast<const float4 *>(a.et + 4 * g);
+    const float4 al = *reinterpret_cast<const float4 *>(a.ra + 4 * g);
+    const float we0 = a.we[(0 + g) * CO + i16], we1 = a.we[(4 + g) * CO + i16];  // A: row co = i16
+    float wsr[6 * 4];  // stacked transposed-conv kernel as A operand, all 6 slots
+#pragma unroll
+    for (int slot = 0; slot < 6; ++slot)
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) wsr[slot * 4 + s_] = a.ws[(slot * PF + 4 * s_ + g) * 16 + i16];
+    __syncthreads();
+
+    // ---- phase B: transposed conv 16 -> 8 (accA rows [ee|eo], accB rows [oe|oo]) -> exp -> gated residual ---
+#pragma unroll
+    for (int k = 0; k < MPW; ++k) {
+        const int t = (wave + 4 * k) * 16 + i16;
+        const int r_ = t / TW, c_ = t - r_ * TW;
+        const int iy = ty0 + r_, ix = tx0 + c_;
+        const bool ok = ipixk[k] >= 0;
         f32x4 accA = {0}, accB = {0};
 #pragma unroll
         for (int slot = 0; slot < 6; ++slot) {
@@ -598,6 +615,8 @@ __global__ __launch_bounds__(256, 3) void k_upsample16(UpArgs a)
         transpose4(qa[0], qa[1], qa[2], qa[3]);
         transpose4(qb[0], qb[1], qb[2], qb[3]);
 
+        const f32x4 res = resk[k];
+        const unsigned cd = codes[k];
         float *yp = yimg + (ok ? ((long)(2 * iy) * (2 * a.W) + 2 * ix) * CO : 0) + 4 * g;
 #pragma unroll
         for (int cls = 0; cls < 4; ++cls) {  // ee, eo, oe, oo == window code dy*2+dx
@@ -607,17 +626,12 @@ __global__ __launch_bounds__(256, 3) void k_upsample16(UpArgs a)
             e = mfma16(we0, b0, e);
             e = mfma16(we1, b1, e);
             float4 o;
-            o.x = prelu1(fmaf(e[0], s1.x, t1.x) + (((codes >> 0) & 0xFFu) == (unsigned)cls ? res[0] : 0.0f), al.x);
-            o.y = prelu1(fmaf(e[1], s1.y, t1.y) + (((codes >> 8) & 0xFFu) == (unsigned)cls ? res[1] : 0.0f), al.y);
-            o.z = prelu1(fmaf(e[2], s1.z, t1.z) + (((codes >> 16) & 0xFFu) == (unsigned)cls ? res[2] : 0.0f), al.z);
-            o.w = prelu1(fmaf(e[3], s1.w, t1.w) + (((codes >> 24) & 0xFFu) == (unsigned)cls ? res[3] : 0.0f), al.w);
+            o.x = prelu1(fmaf(e[0], s1.x, t1.x) + (((cd >> 0) & 0xFFu) == (unsigned)cls ? res[0] : 0.0f), al.x);
+            o.y = prelu1(fmaf(e[1], s1.y, t1.y) + (((cd >> 8) & 0xFFu) == (unsigned)cls ? res[1] : 0.0f), al.y);
+            o.z = prelu1(fmaf(e[2], s1.z, t1.z) + (((cd >> 16) & 0xFFu) == (unsigned)cls ? res[2] : 0.0f), al.z);
+            o.w = prelu1(fmaf(e[3], s1.w, t1.w) + (((cd >> 24) & 0xFFu) == (unsigned)cls ? res[3] : 0.0f), al.w);
             if (ok) *reinterpret_cast<float4 *>(yp + ((cls >> 1) * (2 * a.W) + (cls & 1)) * CO) = o;
         }
-#pragma unroll
-        for (int m = 0; m < 4; ++m) v[m] = vn[m];
-        codes = codesn;
-        ok = okn;
-        ipix = ipixn;
     }
     (void)CF;
 }

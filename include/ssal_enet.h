@@ -157,9 +157,9 @@ int ssal_debug_probe(float *out_dev_256, void *stream);
  * independent accumulators per wave; out_dev needs blocks*256 floats.  Time it with ssal_profile_*. */
 int ssal_debug_mfma_peak(int shape, int blocks, int iters, float *out_dev, void *stream);
 
-/* tuning / A-B knob of the fused bottleneck launchers ("bnk_tw": 16 forces 8x16 tiles, "ablate": phase
- * ablation for timing; defaults come from the SSAL_BNK_TW / SSAL_ABLATE environment).  Every "bnk_tw"
- * setting produces bit-identical results (tests/test_gpu_parity.py); SSAL_EINVAL for an unknown name. */
+/* tuning / A-B knob of the fused bottleneck launchers ("bnk_tw": 16 forces 8x16 tiles, "bnk_xcd": 0 switches
+ * the XCD-aware tile order off, "ablate": phase ablation for timing; defaults come from the SSAL_BNK_TW /
+ * SSAL_BNK_XCD / SSAL_ABLATE environment).  Every "bnk_tw" / "bnk_xcd" setting produces bit-identical results (tests/test_gpu_parity.py); SSAL_EINVAL for an unknown name. */
 int ssal_debug_set_knob(const char *name, int value);
 
 /* measurement aid (tools/mem_probe.py): y = x for an [n,h,w,64] tensor with the access shape `mode`

@@ -1096,6 +1096,7 @@ SSAL_API int ssal_debug_set_knob(const char *name, int value)
     ssal::Knobs &k = ssal::knobs();
     const std::string n(name);
     if (n == "bnk_tw") k.bnk_tw = value;
+    else if (n == "bnk_xcd") k.bnk_xcd = value;
     else if (n == "ablate") k.ablate = value;
     else return fail(SSAL_EINVAL, "unknown knob");
     return SSAL_OK;

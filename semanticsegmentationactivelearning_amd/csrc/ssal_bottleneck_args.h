@@ -19,6 +19,7 @@ struct BnkArgs {
     int TH;                // tile rows (phase space)
     int tiles_y, tiles_x;  // tiles per phase sub-image (sized for the largest phase)
     unsigned long long *trace;  // phase-trace buffer (NULL unless a -DSSAL_PHASE_TRACE build is being traced)
+    int ntiles, xcd_chunk;  // XCD-aware tile order: tile = (b % 8) * xcd_chunk + b / 8 (xcd_chunk = 0: tile = b)
     int ablate;            // measurement aid (SSAL_ABLATE env): 1 = stop after the projection phase,
                            // 2 = skip the projection phase (results invalid; timing only)
 };

@@ -347,6 +347,10 @@ __device__ __forceinline__ TileId decode_tile(const BnkArgs &a)
     TileId t;
     const int d = a.dil;
     int b = blockIdx.x;
+    if (a.xcd_chunk > 0) {  // XCD-aware order: workgroup b runs on XCD b % 8; give every XCD a contiguous run of tiles
+        b = (b & 7) * a.xcd_chunk + (b >> 3);
+        if (b >= a.ntiles) { t.empty = true; return t; }
+    }
     t.TH = a.TH;
     const int tx = b % a.tiles_x; b /= a.tiles_x;
     const int ty = b % a.tiles_y; b /= a.tiles_y;
@@ -990,6 +994,7 @@ Knobs &knobs()
         auto env = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
         Knobs q;
         q.bnk_tw = env("SSAL_BNK_TW", 0);
+        q.bnk_xcd = env("SSAL_BNK_XCD", 1);
         q.ablate = env("SSAL_ABLATE", 0);
         return q;
     }();
@@ -1118,7 +1123,10 @@ hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W,
     a.tiles_x = (Wp + TW - 1) / TW;
     const long grid = (long)N * dil * dil * a.tiles_y * a.tiles_x;
     if (grid <= 0 || grid > 0x7fffffffL) return hipErrorInvalidValue;
-    if (g_trace_buf && grid * 4 * 16 * 8 <= g_trace_bytes) a.trace = g_trace_buf;
+    a.ntiles = (int)grid;
+    a.xcd_chunk = kn.bnk_xcd ? (int)((grid + 7) / 8) : 0;
+    const long launch_grid = kn.bnk_xcd ? 8L * a.xcd_chunk : grid;
+    if (g_trace_buf && launch_grid * 4 * 16 * 8 <= g_trace_bytes) a.trace = g_trace_buf;
     const double pix = (double)N * H * W;
     const double f = Cin / 4.0;
     const double taps = asym ? 10.0 : 9.0;
@@ -1127,14 +1135,14 @@ hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W,
                    4.0 * (2.0 * pix * Cin + Cin * f * 2.0 + taps * f * f), s);
     if (asym) {
         if (wide)
-            hipLaunchKernelGGL(k_bottleneck_mfma_asym<32>, dim3((unsigned)grid), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(k_bottleneck_mfma_asym<32>, dim3((unsigned)launch_grid), dim3(256), 0, s, a);
         else
-            hipLaunchKernelGGL(k_bottleneck_mfma_asym<16>, dim3((unsigned)grid), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(k_bottleneck_mfma_asym<16>, dim3((unsigned)launch_grid), dim3(256), 0, s, a);
     } else {
         if (wide)
-            hipLaunchKernelGGL(k_bottleneck_mfma<32>, dim3((unsigned)grid), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(k_bottleneck_mfma<32>, dim3((unsigned)launch_grid), dim3(256), 0, s, a);
         else
-            hipLaunchKernelGGL(k_bottleneck_mfma<16>, dim3((unsigned)grid), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(k_bottleneck_mfma<16>, dim3((unsigned)launch_grid), dim3(256), 0, s, a);
     }
     return hipGetLastError();
 }

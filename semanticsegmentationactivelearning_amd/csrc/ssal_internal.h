@@ -102,6 +102,7 @@ hipError_t launch_upsample_mfma(const float *x, float *y, const uint8_t *code, i
 // and for the tests that compare the variants bit for bit).
 struct Knobs {
     int bnk_tw;      // 16 = force 8x16 tiles in the 128-channel bottleneck kernels
+    int bnk_xcd;     // 1 = XCD-aware tile order in the 128-channel bottleneck kernels
     int ablate;      // 1 = stop after the projection phase, 2 = skip it (timing only, results invalid)
 };
 Knobs &knobs();

@@ -256,8 +256,8 @@ def test_mfma_bottleneck_equals_generic_and_oracle(enet_c3k19, name, n, h, w):
 
 @pytest.mark.parametrize("name", ["Bottleneck2_1", "Bottleneck2_2", "Bottleneck2_3", "Bottleneck3_8"])
 def test_bottleneck_tile_shapes_bit_identical(enet_c3k19, name):
-    """8x32 and 8x16 tiles of the 128-channel bottleneck kernels must produce the same bits (the launcher
-    picks by width; the knob forces the narrow one), at a size with several tiles per CU"""
+    """8x32 and 8x16 tiles, XCD-aware and plain tile order of the 128-channel bottleneck kernels must produce
+    the same bits, at a size with several tiles per CU"""
     net, P = enet_c3k19
     layer = getattr(net, name)
     x = np.random.default_rng(23).normal(size=(3, 128, 256, 128)).astype(np.float32)
@@ -267,8 +267,13 @@ def test_bottleneck_tile_shapes_bit_identical(enet_c3k19, name):
         _lib.set_knob("bnk_tw", 16)
         got = layer(xd, training=False)
         assert torch.equal(got, ref), "8x16 tiles differ from 8x32 tiles"
+        _lib.set_knob("bnk_tw", 0)
+        _lib.set_knob("bnk_xcd", 0)
+        got = layer(xd, training=False)
+        assert torch.equal(got, ref), "plain tile order differs from the XCD-aware order"
     finally:
         _lib.set_knob("bnk_tw", 0)
+        _lib.set_knob("bnk_xcd", 1)
     want = orc.bottleneck(P, name, x[1:2], dil=layer.dilation_rate[0], asym=layer.asymmetric)
     report_diff(name + " [128,256] vs oracle (bit-exact)", ref[1:2].cpu().numpy(), want)
 

@@ -34,6 +34,7 @@ struct DownArgs {
     const float *we, *es, *et, *ra;  // exp kernel [32][128]
     int N, H, W;                     // INPUT dims (even)
     int TH, tiles_y, tiles_x;
+    unsigned long long *trace;       // phase-trace buffer (NULL unless a -DSSAL_PHASE_TRACE build is being traced)
 };
 
 // upsample bottleneck (enet_modules.py:1217-1292)
@@ -49,6 +50,7 @@ struct UpArgs {
     const float *ra;                 // [64]
     int N, H, W, dil;                // dil == 1
     int TH, tiles_y, tiles_x;
+    unsigned long long *trace;       // phase-trace buffer (NULL unless a -DSSAL_PHASE_TRACE build is being traced)
 };
 
 }  // namespace ssal

@@ -464,6 +464,8 @@ __global__ __launch_bounds__(256, 2) void k_downsample_mfma(DownArgs a)
     const float *ximg = a.x + (long)n * a.H * a.W * CDN;
     float *yimg = a.y + (long)n * Ho * Wo * C;
     uint8_t *cimg = a.code + (long)n * Ho * Wo * CDN;
+    PhaseTrace tr;
+    tr.mark(0);
 
     for (int i = threadIdx.x; i < F * C / 4; i += 256)
         reinterpret_cast<float4 *>(WE)[i] = reinterpret_cast<const float4 *>(a.we)[i];
@@ -573,6 +575,7 @@ __global__ __launch_bounds__(256, 2) void k_downsample_mfma(DownArgs a)
         project(xp, (unsigned)__ballot(rvalid), [&](int ri) { return q_ring(wave * 32 + ri); }, false, dummy_best,
                 dummy_code);
     }
+    tr.mark(1);  // ring tile projected
 #pragma unroll
     for (int k = 0; k < MPW; ++k) {
         const int mt = wave + 4 * k;
@@ -591,7 +594,9 @@ __global__ __launch_bounds__(256, 2) void k_downsample_mfma(DownArgs a)
                 *reinterpret_cast<unsigned *>(cimg + opixk[k] * CDN + 8 * m + 4 * h) = code[m];
         }
     }
+    tr.mark(2);  // centre tiles projected and pooled
     __syncthreads();
+    tr.mark(3);
 
     // ---- phase B: 3x3 conv -> expansion D[co][pixel] -> + pooled residual (registers) -> float4 stores ----
     const float *wel = WE + h * C + j;  // We[2s + h][nt*32 + j] = wel[2s*C + nt*32]
@@ -601,6 +606,7 @@ __global__ __launch_bounds__(256, 2) void k_downsample_mfma(DownArgs a)
         const int mt = wave + 4 * k;
         float qv[16];
         conv_tile_q<TW, 3, 3, HW2>(a, P, a.wc, mt, j, h, qv);
+        if (k == 0) tr.mark(4);  // first conv done
         float *yp = yimg + (opixk[k] >= 0 ? opixk[k] : 0) * C + 4 * h;
         auto chain = [&](int nt, int s, f32x16 e) { return mfma32(wel[2 * s * C + nt * 32], qv[ord(s)], e); };
         auto epilogue = [&](int nt, int g, const f32x16 &e) {
@@ -640,7 +646,14 @@ __global__ __launch_bounds__(256, 2) void k_downsample_mfma(DownArgs a)
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) epilogue(3, g, e1);
+        if (k == 0) tr.mark(5);  // first M-tile stored (issued)
     }
+    tr.mark(6);
+#ifdef SSAL_PHASE_TRACE
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    tr.mark(7);
+    tr.flush(a.trace, lane, wave);
 }
 
 // =================================================================================================
@@ -688,6 +701,8 @@ __global__ __launch_bounds__(256, 2) void k_upsample_mfma(UpArgs a)
     const float *ximg = a.x + (long)n * a.H * a.W * C;
     const uint8_t *cimg = a.code + (long)n * a.H * a.W * CUP;
     float *yimg = a.y + (long)n * 4 * a.H * a.W * CUP;
+    PhaseTrace tr;
+    tr.mark(0);
 
     if (threadIdx.x < 3 * CUP / 4) {
         const int arr = threadIdx.x / (CUP / 4), k4 = threadIdx.x % (CUP / 4);
@@ -779,6 +794,7 @@ __global__ __launch_bounds__(256, 2) void k_upsample_mfma(UpArgs a)
         f32x16 d0 = {0}, d1 = {0};
         project(xp, (unsigned)__ballot(rvalid), [&](int ri) { return q_ring(wave * 32 + ri); }, std::false_type(), d0, d1);
     }
+    tr.mark(1);  // ring tile projected
 #pragma unroll
     for (int k = 0; k < MPW; ++k) {
         const int mt = wave + 4 * k;
@@ -805,7 +821,9 @@ __global__ __launch_bounds__(256, 2) void k_upsample_mfma(UpArgs a)
 #pragma unroll
             for (int s = 0; s < 8; ++s) wef[nt][s] = bload(wers, wrlo, s * 512 + nt * 128);  // We[2s + h][nt*32 + j]
     }
+    tr.mark(2);  // centre tiles projected (+ residual conv)
     __syncthreads();
+    tr.mark(3);
 
     // ---- phase B: transposed conv (2 stacked accumulators) -> expansion per parity class -> unpool-gated
     // residual -> float4 stores ----------------------------------------------------------------------------
@@ -861,6 +879,7 @@ __global__ __launch_bounds__(256, 2) void k_upsample_mfma(UpArgs a)
             __builtin_amdgcn_sched_barrier(0);
             run_slot(accB, wB, pB);
         }
+        if (k == 0) tr.mark(4);  // first transposed conv done
         // BN + PReLU; reg i: class = i >> 3, channel = (i&3) + 8*((i>>2)&1) + 4h
         float qa[16], qb[16];
 #pragma unroll
@@ -920,7 +939,14 @@ __global__ __launch_bounds__(256, 2) void k_upsample_mfma(UpArgs a)
             if (m + 2 < 8) e0 = chain(m + 2, (f32x16){0});
             epilogue(m + 1, e1);
         }
+        if (k == 0) tr.mark(5);  // first M-tile stored (issued)
     }
+    tr.mark(6);
+#ifdef SSAL_PHASE_TRACE
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    tr.mark(7);
+    tr.flush(a.trace, lane, wave);
 }
 
 // one probe for the hardware assumptions this file rests on (tests only): out[0..63] / out[64..127]
@@ -1032,6 +1058,7 @@ hipError_t launch_downsample_mfma(const float *x, float *y, uint8_t *code, int N
     if (H % 2 || W % 2) return hipErrorInvalidValue;
     DownArgs a;
     a.x = x; a.y = y; a.code = code;
+    a.trace = nullptr;
     a.wp = wp; a.ps = ps; a.pt = pt; a.pa = pa;
     a.wc = wc; a.cs = cs; a.ct = ct; a.ca = ca;
     a.we = we; a.es = es; a.et = et; a.ra = ra;
@@ -1045,6 +1072,7 @@ hipError_t launch_downsample_mfma(const float *x, float *y, uint8_t *code, int N
     a.tiles_x = (Wo + TW - 1) / TW;
     const long grid = (long)N * a.tiles_y * a.tiles_x;
     if (grid <= 0 || grid > 0x7fffffffL) return hipErrorInvalidValue;
+    a.trace = (g_trace_buf && grid * 4 * 16 * 8 <= g_trace_bytes) ? g_trace_buf : nullptr;
     const double opix = (double)N * Ho * Wo;
     ProfScope prof("k_downsample_mfma", 2.0 * opix * (4.0 * CDN * F + 9.0 * F * F + F * (double)C),
                    4.0 * (4.0 * opix * CDN + opix * C) + opix * CDN, s);
@@ -1068,6 +1096,7 @@ hipError_t launch_upsample_mfma(const float *x, float *y, const uint8_t *code, i
 {
     UpArgs a;
     a.x = x; a.y = y; a.code = code;
+    a.trace = nullptr;
     a.wp = wp; a.ps = ps; a.pt = pt; a.pa = pa;
     a.ws = ws; a.cs = cs; a.ct = ct; a.ca = ca;
     a.we = we; a.es = es; a.et = et; a.wr = wr; a.ra = ra;
@@ -1080,6 +1109,7 @@ hipError_t launch_upsample_mfma(const float *x, float *y, const uint8_t *code, i
     a.tiles_x = (W + TW - 1) / TW;
     const long grid = (long)N * a.tiles_y * a.tiles_x;
     if (grid <= 0 || grid > 0x7fffffffL) return hipErrorInvalidValue;
+    a.trace = (g_trace_buf && grid * 4 * 16 * 8 <= g_trace_bytes) ? g_trace_buf : nullptr;
     const double pix = (double)N * H * W;
     ProfScope prof("k_upsample_mfma",
                    2.0 * pix * (C * 32.0 + 9.0 * 32 * 16 + 4.0 * 16 * CUP + C * (double)CUP),

@@ -22,12 +22,15 @@ def build_trace_lib():
 LAYER_SHAPE = {  # name -> (H divisor, channels in)
     "Bottleneck1_1": (4, 64), "Bottleneck2_1": (8, 128), "Bottleneck2_2": (8, 128), "Bottleneck2_4": (8, 128),
     "Bottleneck2_6": (8, 128), "Bottleneck2_8": (8, 128), "Bottleneck5_1": (2, 16),
+    "Bottleneck2_3": (8, 128), "Bottleneck2_0": (4, 64), "Bottleneck4_0": (8, 128),
 }
 MARKS = {
     "Bottleneck2": ["start", "proj done", "barrier", "conv mt0", "exp mt0", "conv mt1", "exp mt1", "stores acked"],
     "Bottleneck1": ["start", "centre proj", "ring+opnds", "barrier", "conv mt0", "store mt0", "all issued", "stores acked"],
     "Bottleneck5": ["start", "centre proj", "ring+opnds", "barrier", "conv mt0", "store mt0", "all issued", "stores acked"],
+    "Bottleneck4": ["start", "ring proj", "centre proj", "barrier", "conv mt0", "store mt0", "all issued", "stores acked"],
 }
+MARKS_BY_LAYER = {"Bottleneck2_0": MARKS["Bottleneck4"]}
 
 
 def main():
@@ -53,20 +56,24 @@ def main():
         h, w = H // div, W // div
         x = torch.randn(n, h, w, cin, device="cuda")
         layer = [l for l in net.layers if l.name == name][0]
+        amax = None
+        if name == "Bottleneck4_0":  # an upsample block needs the pooling indices of its downsample twin
+            down = [l for l in net.layers if l.name == "Bottleneck2_0"][0]
+            _, amax = net._run_layer(down, torch.randn(n, 2 * h, 2 * w, 64, device="cuda"), None, True)
         for _ in range(2):
-            net._run_layer(layer, x, None, False)
+            net._run_layer(layer, x, amax, False)
         nbytes = 64 << 20
         buf = torch.zeros(nbytes // 8, dtype=torch.int64, device="cuda")
         _lib.check(L.ssal_debug_set_trace(_lib.dev_ptr(buf), nbytes))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); net._run_layer(layer, x, None, False); e1.record()
+        e0.record(); net._run_layer(layer, x, amax, False); e1.record()
         torch.cuda.synchronize()
         _lib.check(L.ssal_debug_set_trace(None, 0))
         t = buf.cpu().numpy().reshape(-1, 16)
         wg_of_row = np.arange(len(t)) // 4
         keep = t[:, 0] != 0
         t, wg_of_row = t[keep], wg_of_row[keep]
-        marks = MARKS[name[:11]]
+        marks = MARKS_BY_LAYER.get(name, MARKS[name[:11]])
         print("\n=== %s  [%d,%d,%d,%d]  %d waves traced, launch %.1f us (incl. host gaps)" % (name, n, h, w, cin, len(t), 1e3 * e0.elapsed_time(e1)))
         cyc = (t[:, 7] - t[:, 0]).astype(np.float64)
         rt = (t[:, 13] - t[:, 12]).astype(np.float64) * 10e-9  # 100 MHz

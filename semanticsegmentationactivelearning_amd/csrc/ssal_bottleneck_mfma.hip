@@ -691,8 +691,10 @@ __global__ __launch_bounds__(256, 2) void k_upsample_mfma(UpArgs a)
     constexpr int QDUMP = PMAX - 1;          // spare P row for M-tile pixels beyond the ring
     __shared__ float P[PMAX * PSTR];
     __shared__ float BNV[3 * CUP + 3 * 16];  // es | et | ra (64 each), then cs | ct | ca (16 each)
+    __shared__ float WEL[16 * CUP];          // expansion kernel [ci 16][co 64]: A operand of the flipped expansion
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
+    reinterpret_cast<float4 *>(WEL)[threadIdx.x] = reinterpret_cast<const float4 *>(a.we)[threadIdx.x];  // 256 x float4
     int b = blockIdx.x;
     const int tx = b % a.tiles_x; b /= a.tiles_x;
     const int ty = b % a.tiles_y; b /= a.tiles_y;
@@ -783,7 +785,6 @@ __global__ __launch_bounds__(256, 2) void k_upsample_mfma(UpArgs a)
     };
 
     f32x16 res[MPW][2];    // residual 1x1 conv of the lane's centre pixel: reg 4g + c = channel nt*32 + 8g + 4h + c
-    unsigned codes[MPW][8];  // window codes of channels nt*32 + 8g + 4h .. +3 (index 4 nt + g), one byte each
     long ipixk[MPW];         // input pixel index of the lane's centre pixel, -1 outside the image
     if (wave < NRMT) {       // wave-uniform: this wave's ring tile
         const int u = wave * 32 + j;
@@ -803,24 +804,13 @@ __global__ __launch_bounds__(256, 2) void k_upsample_mfma(UpArgs a)
         const bool valid = iy < a.H && ix < a.W;
         ipixk[k] = valid ? (long)iy * a.W + ix : -1;
         const float *xp = valid ? ximg + ipixk[k] * C : ximg;
-        const uint8_t *cp = cimg + (valid ? ipixk[k] : 0) * CUP + 4 * h;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) codes[k][q] = *reinterpret_cast<const unsigned *>(cp + 8 * q);  // nt*32 + 8g = 8 (4nt + g)
         res[k][0] = (f32x16){0};
         res[k][1] = (f32x16){0};
         project(xp, (unsigned)__ballot(valid),
                 [&](int ri) { const int t2 = mt * 32 + ri; return (t2 / TW + 1) * HW2 + (t2 % TW) + 1; },
                 std::true_type(), res[k][0], res[k][1]);
     }
-    // expansion kernel (16 -> 64) as A operand of the flipped expansion: lane (r = j, k = h)
-    float wef[2][8];
-    {
-        const rsrc_t wers = make_rsrc(a.we, 16 * CUP * 4);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int s = 0; s < 8; ++s) wef[nt][s] = bload(wers, wrlo, s * 512 + nt * 128);  // We[2s + h][nt*32 + j]
-    }
+    const float *wel = WEL + h * CUP + j;  // We[2s + h][nt*32 + j] = wel[2s*CUP + nt*32]: lane (r = j, k = h)
     tr.mark(2);  // centre tiles projected (+ residual conv)
     __syncthreads();
     tr.mark(3);
@@ -834,6 +824,14 @@ __global__ __launch_bounds__(256, 2) void k_upsample_mfma(UpArgs a)
         const int mt = wave + 4 * k;
         const int t = mt * 32 + j;
         const int r = t / TW, c = t - r * TW;
+        // window codes of channels nt*32 + 8g + 4h .. +3 (index 4 nt + g), one byte each; requested here (needed
+        // only by the epilogues below), ahead of this M-tile's stores
+        unsigned codes[8];
+        {
+            const uint8_t *cp = cimg + (ipixk[k] >= 0 ? ipixk[k] : 0) * CUP + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) codes[q] = *reinterpret_cast<const unsigned *>(cp + 8 * q);  // nt*32 + 8g = 8 (4nt + g)
+        }
         f32x16 accA = {0}, accB = {0};
         {
             float wA[16], wB[16];
@@ -909,7 +907,7 @@ __global__ __launch_bounds__(256, 2) void k_upsample_mfma(UpArgs a)
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const float qv = cls < 2 ? qa[(cls & 1) * 8 + ord(s)] : qb[(cls & 1) * 8 + ord(s)];
-                e = mfma32(wef[nt][s], qv, e);
+                e = mfma32(wel[2 * s * CUP + nt * 32], qv, e);
             }
             return e;
         };
@@ -918,10 +916,13 @@ __global__ __launch_bounds__(256, 2) void k_upsample_mfma(UpArgs a)
             float *yp = yq + ((cls >> 1) * (2 * a.W) + (cls & 1)) * CUP + nt * 32;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                // keep the three LDS vector reads here: hoisted out of the class loop (they do not depend on
+                // cls) they would pin 96 registers and push the residual into scratch
+                asm volatile("" ::: "memory");
                 const float4 s4 = *reinterpret_cast<const float4 *>(bnl + nt * 32 + 8 * g);
                 const float4 t4 = *reinterpret_cast<const float4 *>(bnl + CUP + nt * 32 + 8 * g);
                 const float4 a4 = *reinterpret_cast<const float4 *>(bnl + 2 * CUP + nt * 32 + 8 * g);
-                const unsigned cd = codes[k][4 * nt + g];
+                const unsigned cd = codes[4 * nt + g];
                 const f32x16 &rs = res[k][nt];
                 float4 o;  // unpool_2d as a gather: the residual lands on the output parity its window code names
                 o.x = prelu1(fmaf(e[4 * g + 0], s4.x, t4.x) + (((cd >> 0) & 0xFFu) == (unsigned)cls ? rs[4 * g + 0] : 0.0f), a4.x);

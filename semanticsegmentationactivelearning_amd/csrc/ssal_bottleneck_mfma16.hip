@@ -520,30 +520,33 @@ __global__ __launch_bounds__(256, 3) void k_upsample16(UpArgs a)
 
     float4 vk[MPW][NT], vr[RM][NT];
     unsigned codes[MPW];  // window codes of channels 4g..4g+3 of the lane's centre pixel
-    long ipixk[MPW];      // input pixel index of the lane's centre pixel, -1 outside the image
+    int ipixk[MPW];       // input pixel index of the lane's centre pixel (< 2^31: guarded by the API), -1 outside the image
     bool rvalid[RM];
 #pragma unroll
     for (int k = 0; k < MPW; ++k) {
         const int t = (wave + 4 * k) * 16 + i16;
         const int iy = ty0 + t / TW, ix = tx0 + t % TW;
         const bool valid = (iy < a.H) && (ix < a.W);
-        ipixk[k] = valid ? (long)iy * a.W + ix : -1;
-        load_frags(ximg + (valid ? ipixk[k] : 0) * CI, vk[k]);
-        codes[k] = *reinterpret_cast<const unsigned *>(cimg + (valid ? ipixk[k] : 0) * CO + 4 * g);
-    }
-#pragma unroll
-    for (int k = 0; k < RM; ++k) {
-        const int u = (wave + 4 * k) * 16 + i16;
-        const int q = u < RING ? q_ring(u) : 0;
-        const int pr = ty0 - 1 + q / HW2, pc = tx0 - 1 + q % HW2;
-        rvalid[k] = (u < RING) && (pr >= 0) && (pr < a.H) && (pc >= 0) && (pc < a.W);
-        load_frags(rvalid[k] ? ximg + ((long)pr * a.W + pc) * CI : ximg, vr[k]);
+        ipixk[k] = valid ? iy * a.W + ix : -1;
+        load_frags(ximg + (long)(valid ? ipixk[k] : 0) * CI, vk[k]);
+        codes[k] = *reinterpret_cast<const unsigned *>(cimg + (long)(valid ? ipixk[k] : 0) * CO + 4 * g);
     }
     __builtin_amdgcn_sched_barrier(0);
 
     f32x4 resk[MPW];  // residual conv of the centre pixel: reg r = channel 4g + r
 #pragma unroll
     for (int k = 0; k < MPW; ++k) {
+        if (k == MPW / 2) {  // the ring fragments are requested once half of the centre registers are free again
+#pragma unroll
+            for (int kr = 0; kr < RM; ++kr) {
+                const int u = (wave + 4 * kr) * 16 + i16;
+                const int q = u < RING ? q_ring(u) : 0;
+                const int pr = ty0 - 1 + q / HW2, pc = tx0 - 1 + q % HW2;
+                rvalid[kr] = (u < RING) && (pr >= 0) && (pr < a.H) && (pc >= 0) && (pc < a.W);
+                load_frags(rvalid[kr] ? ximg + ((long)pr * a.W + pc) * CI : ximg, vr[kr]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         const int mt = wave + 4 * k;
         const unsigned vmask = (unsigned)(__ballot(ipixk[k] >= 0) & 0xFFFFull);
         int qrow[4];

@@ -122,18 +122,17 @@ __device__ __forceinline__ void proj_to_lds(const Args &a, const float *ximg, fl
 
 // ---- asymmetric only: R1 = conv (5,1) of P, no BN / activation (enet_modules.py:553-558), for the
 // TH x (TW+4) pixels the (1,5) conv needs; D[pixel][co] = P[pixel + kh][ci] * W0[kh][ci][co] -> LDS.
-// R rows = RH consecutive tile rows starting at tile row r0; the last M-tile may run past RH*HWP pixels:
-// its surplus rows read LDS beyond the rows they need (inside the allocation) and are never used.
+// computes nmt M-tiles of the (5,1) result, pixels u0 .. u0 + 32 nmt - 1 of the row-major 8 x HWP result grid,
+// into R slots 0 .. 32 nmt - 1
 template <int TW>
-__device__ __forceinline__ void conv5x1_to_lds(const BnkArgs &a, const float *P, float *R, int r0, int RH,
+__device__ __forceinline__ void conv5x1_to_lds(const BnkArgs &a, const float *P, float *R, int u0, int nmt,
                                                int wave, int j, int h)
 {
     constexpr int HWP = TW + 4;
-    const int nmt = (RH * HWP + 31) / 32;  // RH = 4: 5 (TW 32) or 3 (TW 16) M-tiles
     const rsrc_t wrs = make_rsrc(a.wc, 5 * F * F * 4);
     const unsigned lo = (unsigned)(h * 32 + j) * 4u;
     for (int mt = wave; mt < nmt; mt += 4) {
-        const int u = mt * 32 + j;
+        const int u = u0 + mt * 32 + j;
         f32x16 acc = {0};
         // one tap ahead, as in conv_tile_q: kernel fragments (L1/L2) and LDS fragments of tap kh+1 are
         // requested before the 16 MFMAs of tap kh
@@ -142,7 +141,7 @@ __device__ __forceinline__ void conv5x1_to_lds(const BnkArgs &a, const float *P,
         auto load_tap = [&](int kh, float (&w)[16], float2 (&pv)[8]) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) w[k] = bload(wrs, lo, kh * (F * F * 4) + k * 256);  // W0[kh][2k + h][j]
-            const float *pq = P + (u + (r0 + kh) * HWP) * PSTR + 2 * h;  // pixel (r0 + r + kh, c')
+            const float *pq = P + (u + kh * HWP) * PSTR + 2 * h;  // result pixel u = (r, c') reads P rows r + kh
 #pragma unroll
             for (int sq = 0; sq < 8; ++sq) pv[sq] = *reinterpret_cast<const float2 *>(pq + 4 * sq);
         };
@@ -179,9 +178,11 @@ __device__ __forceinline__ void conv5x1_to_lds(const BnkArgs &a, const float *P,
 // ---- KH x KW conv (F -> F) over an LDS tensor S (row stride SW pixels) for one 32-pixel M-tile,
 // + BN + PReLU; returns the result as the A operand of the following expansion GEMM:
 // qv[ord(s)] of lane (pixel j, half h) = Q[pixel][ci = 2s + h].
-template <int TW, int KH, int KW, int SW, typename Args>
+// WRAP > 0 (asymmetric block, second half): S is a ring of WRAP pixel slots, the pixel index is shifted by
+// soff (< 0) and indices that become negative wrap to the end of the ring.
+template <int TW, int KH, int KW, int SW, typename Args, int WRAP = 0>
 __device__ __forceinline__ void conv_tile_q(const Args &a, const float *S, const float *wconv, int mt,
-                                            int j, int h, float (&qv)[16])
+                                            int j, int h, float (&qv)[16], int soff = 0)
 {
     const int t = mt * 32 + j;  // this lane's output pixel inside the tile (B operand)
     const int r = t / TW, c = t - r * TW;
@@ -200,7 +201,12 @@ __device__ __forceinline__ void conv_tile_q(const Args &a, const float *S, const
 #pragma unroll
         for (int k = 0; k < 16; ++k)  // W[tap][ci = 2k + h][co = j]: rows 2k, 2k+1 = 64 consecutive floats
             w[k] = bload(wrs, lo, tap * (F * F * 4) + k * 256);
-        const float *pq = S + ((r + kh) * SW + (c + kw)) * PSTR + 2 * h;
+        int slot = (r + kh) * SW + (c + kw);
+        if (WRAP > 0) {
+            slot += soff;
+            slot = slot < 0 ? slot + WRAP : slot;
+        }
+        const float *pq = S + slot * PSTR + 2 * h;
 #pragma unroll
         for (int sq = 0; sq < 8; ++sq) p[sq] = *reinterpret_cast<const float2 *>(pq + 4 * sq);
     };
@@ -246,11 +252,11 @@ __device__ __forceinline__ void conv_tile_q(const Args &a, const float *S, const
 
 // ---- last phase of the regular / asymmetric bottleneck: conv, then 1x1 expansion + BN + identity
 // residual + PReLU straight to HBM.
-template <int TW, int KH, int KW, int SW>
+template <int TW, int KH, int KW, int SW, int WRAP = 0>
 __device__ __forceinline__ void conv_exp_store(const BnkArgs &a, const float *ximg, float *yimg,
                                                const float *S, const float *wconv, int TH, int ty0,
                                                int tx0, int py, int px, int Hp, int Wp, int wave,
-                                               int j, int h, PhaseTrace &tr)
+                                               int j, int h, PhaseTrace &tr, int soff = 0)
 {
     const int d = a.dil;
     const int nmt_out = (TH * TW) / 32;
@@ -266,7 +272,7 @@ __device__ __forceinline__ void conv_exp_store(const BnkArgs &a, const float *xi
     const unsigned welo = (unsigned)(h * C + j) * 4u;
     for (int mt = wave; mt < nmt_out; mt += 4) {
         float qv[16];
-        conv_tile_q<TW, KH, KW, SW>(a, S, wconv, mt, j, h, qv);
+        conv_tile_q<TW, KH, KW, SW, BnkArgs, WRAP>(a, S, wconv, mt, j, h, qv, soff);
         tr.mark(trk++);  // 3, 5: conv of this wave's 1st / 2nd M-tile done
 
         // BYTE offsets (inside image n) of the 16 output rows this lane-half stores, lane channel folded
@@ -394,9 +400,12 @@ __global__ __launch_bounds__(256, 3) void k_bottleneck_mfma(BnkArgs a)
 }
 
 // asymmetric bottleneck: (5,1) then (1,5) with no BN / activation in between (dilation 1).
-// LDS: P = the projected tile with a 2-pixel halo (12 x 36 pixels), R = the (5,1) result for FOUR tile
-// rows at a time (4 x 36 pixels, + the tail of the last M-tile): the tile is finished in two halves, which
-// keeps the workgroup at 80.5 KB of LDS = two workgroups per CU (all 8 rows at once: 100 KB = one).
+// LDS: P = the projected tile with a 2-pixel halo (12 x 36 pixels), R = a ring of RROWS pixel slots of the (5,1)
+// result: the tile is finished in two halves, which keeps the workgroup at 80.5 KB of LDS = two workgroups per
+// CU (all 8 rows at once: 100 KB = one).  The first half computes whole M-tiles covering its 4 rows (144
+// pixels -> 160 = 5 M-tiles: the 16 surplus pixels are the start of row 4 and stay where they are), the second
+// half the remaining 128 pixels = exactly 4 M-tiles, written over the slots of rows 0..3: pixel p of the
+// second half lives in slot (p - 160) mod 160.
 constexpr int PROWS_ASYM = 432;  // (8+4)*(32+4)
 constexpr int RROWS_ASYM = 160;  // 5 M-tiles of 32 >= 4*(32+4)
 template <int TW>
@@ -410,15 +419,37 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck_mfma_asym(BnkArgs a)
     if (t.empty) return;
     const float *ximg = a.x + (long)t.n * a.H * a.W * C;
     float *yimg = a.y + (long)t.n * a.H * a.W * C;
+    PhaseTrace tr, tr_inner;  // tr_inner: the per-M-tile marks of conv_exp_store are not kept here
+    tr.mark(0);
     proj_to_lds<TW, 2>(a, ximg, P, t.TH, t.ty0, t.tx0, t.py, t.px, t.Hp, t.Wp, wave, j, h, PROWS_ASYM);
-    PhaseTrace tr;
-    for (int r0 = 0; r0 < t.TH; r0 += 4) {
-        __syncthreads();  // P complete (first half) / R free again (second half)
-        conv5x1_to_lds<TW>(a, P, R, r0, 4, wave, j, h);
+    tr.mark(1);
+    constexpr int HWP = TW + 4;
+    constexpr int NMT0 = (4 * HWP + 31) / 32;        // M-tiles of the first half: 5 (TW 32) / 3 (TW 16)
+    constexpr int NMT1 = (8 * HWP) / 32 - NMT0;      // the rest: 4 / 2 (8 * HWP is a multiple of 32)
+    constexpr int RING = NMT0 * 32;                  // ring size in pixel slots: 160 / 96
+    __syncthreads();  // P complete
+    tr.mark(2);
+    conv5x1_to_lds<TW>(a, P, R, 0, NMT0, wave, j, h);
+    tr.mark(3);
+    __syncthreads();
+    tr.mark(4);
+    conv_exp_store<TW, 1, 5, HWP>(a, ximg, yimg, R, a.wc2, 4, t.ty0, t.tx0, t.py, t.px, t.Hp, t.Wp, wave, j, h,
+                                  tr_inner);
+    tr.mark(5);
+    if (t.TH > 4) {
+        __syncthreads();  // rows 0..3 of R are free again
+        conv5x1_to_lds<TW>(a, P, R, RING, NMT1, wave, j, h);
         __syncthreads();
-        conv_exp_store<TW, 1, 5, TW + 4>(a, ximg, yimg, R, a.wc2, 4, t.ty0 + r0, t.tx0, t.py, t.px, t.Hp,
-                                         t.Wp, wave, j, h, tr);
+        // second half: tile row 4 + r, column c' = result pixel (4 + r) * HWP + c' = slot r * HWP + c' - (RING - 4 * HWP)
+        conv_exp_store<TW, 1, 5, HWP, RING>(a, ximg, yimg, R, a.wc2, 4, t.ty0 + 4, t.tx0, t.py, t.px, t.Hp, t.Wp,
+                                            wave, j, h, tr_inner, -(RING - 4 * HWP));
     }
+    tr.mark(6);
+#ifdef SSAL_PHASE_TRACE
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    tr.mark(7);
+    tr.flush(a.trace, lane, wave);
 }
 
 // =================================================================================================

@@ -30,7 +30,8 @@ MARKS = {
     "Bottleneck5": ["start", "centre proj", "ring+opnds", "barrier", "conv mt0", "store mt0", "all issued", "stores acked"],
     "Bottleneck4": ["start", "ring proj", "centre proj", "barrier", "conv mt0", "store mt0", "all issued", "stores acked"],
 }
-MARKS_BY_LAYER = {"Bottleneck2_0": MARKS["Bottleneck4"]}
+MARKS_BY_LAYER = {"Bottleneck2_0": MARKS["Bottleneck4"],
+                  "Bottleneck2_3": ["start", "proj done", "barrier", "5x1 half0", "barrier", "1x5+exp half0", "half1 done", "stores acked"]}
 
 
 def main():

@@ -19,6 +19,24 @@ __global__ __launch_bounds__(256) void k_probe_linear(const float4 *x, float4 *y
 //   FRAG = false: lane l moves bytes [1024 m + 16 l, +16) of the 4 KB group              (fully coalesced)
 //   HALO        : additionally reads the one-pixel ring of the tile (as phase A does), result discarded
 //   SPIN        : shader-clock cycles of dependent ALU work between the loads and the stores
+// modes 10..13: linear addressing again, but U float4 per thread like the tile kernels: workgroup b owns the
+// contiguous chunk of 256 * U float4; BATCH: all U loads, then all U stores; else load/store pairs in a loop
+template <int U, bool BATCH>
+__global__ __launch_bounds__(256) void k_probe_linear_u(const float4 *x, float4 *y, long n4)
+{
+    const long base = (long)blockIdx.x * 256 * U + threadIdx.x;
+    if (BATCH) {
+        float4 v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) v[k] = base + 256 * k < n4 ? x[base + 256 * k] : make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < U; ++k) if (base + 256 * k < n4) y[base + 256 * k] = v[k];
+    } else {
+#pragma unroll 1
+        for (int k = 0; k < U; ++k) if (base + 256 * k < n4) y[base + 256 * k] = x[base + 256 * k];
+    }
+}
+
 // mode 9: the same 8 x 32 tile, but each wave moves its four 16-pixel groups one after the other
 // (4 loads, 4 stores, next group) instead of 16 loads followed by 16 stores
 __global__ __launch_bounds__(256) void k_probe_tile_seq(const float *x, float *y, int H, int W)
@@ -112,7 +130,7 @@ hipError_t launch_copy_probe(int mode, const float *x, float *y, int N, int H, i
     const long n = (long)N * H * W * 64;
     static const char *names[] = {"probe linear", "probe tile frag", "probe tile coalesced", "probe tile frag+halo",
                                   "probe tile coalesced+halo"};
-    if (mode < 0 || mode > 9) return hipErrorInvalidValue;
+    if (mode < 0 || mode > 13) return hipErrorInvalidValue;
     ProfScope prof(mode <= 4 ? names[mode] : "probe tile shape", 0.0, 8.0 * n, s);
     const unsigned tiles = (unsigned)((long)N * (H / 8) * (W / 32));
     switch (mode) {
@@ -128,6 +146,14 @@ hipError_t launch_copy_probe(int mode, const float *x, float *y, int N, int H, i
     case 7: hipLaunchKernelGGL((k_probe_tile<true, false, 1, 256>), dim3(tiles), dim3(256), 0, s, x, y, H, W, spin); break;
     case 8: hipLaunchKernelGGL((k_probe_tile<true, false, 16, 16>), dim3(tiles), dim3(256), 0, s, x, y, H, W, spin); break;
     case 9: hipLaunchKernelGGL(k_probe_tile_seq, dim3(tiles), dim3(256), 0, s, x, y, H, W); break;
+    case 10: hipLaunchKernelGGL((k_probe_linear_u<16, true>), dim3((unsigned)((n / 4 + 4095) / 4096)), dim3(256), 0, s,
+                                (const float4 *)x, (float4 *)y, n / 4); break;
+    case 11: hipLaunchKernelGGL((k_probe_linear_u<16, false>), dim3((unsigned)((n / 4 + 4095) / 4096)), dim3(256), 0, s,
+                                (const float4 *)x, (float4 *)y, n / 4); break;
+    case 12: hipLaunchKernelGGL((k_probe_linear_u<4, true>), dim3((unsigned)((n / 4 + 1023) / 1024)), dim3(256), 0, s,
+                                (const float4 *)x, (float4 *)y, n / 4); break;
+    case 13: hipLaunchKernelGGL((k_probe_linear_u<2, true>), dim3((unsigned)((n / 4 + 511) / 512)), dim3(256), 0, s,
+                                (const float4 *)x, (float4 *)y, n / 4); break;
     }
     return hipGetLastError();
 }

@@ -8,7 +8,9 @@ L = _lib.lib()
 n, h, w = (int(sys.argv[1]) if len(sys.argv) > 1 else 8), 256, 512
 x = torch.randn(n, h, w, 64, device="cuda"); y = torch.empty_like(x); y2 = torch.empty_like(x)
 names = ["linear", "tile 8x32 frag", "tile 8x32 coalesced", "tile 8x32 frag+halo", "tile 8x32 coalesced+halo",
-         "tile 4x64 frag", "tile 2x128 frag", "tile 1x256 frag", "tile 16x16 frag", "tile 8x32 frag, group by group"]
+         "tile 4x64 frag", "tile 2x128 frag", "tile 1x256 frag", "tile 16x16 frag", "tile 8x32 frag, group by group",
+         "linear, 16 float4/thread batch", "linear, 16 float4/thread loop", "linear, 4 float4/thread batch",
+         "linear, 2 float4/thread batch"]
 def run(mode, spin, reps=20, out=y):
     _lib.check(L.ssal_debug_copy_probe(mode, _lib.dev_ptr(x), _lib.dev_ptr(out), n, h, w, spin, _lib.stream_ptr()))
     torch.cuda.synchronize()

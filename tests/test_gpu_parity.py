@@ -385,6 +385,22 @@ def test_forward_ragged_shapes(enet_c3k19, n, h, w):
     _check_forward(net, P, x, "%dx%dx%d" % (n, h, w))
 
 
+@pytest.mark.parametrize("classes,c_in", [(2, 3), (3, 1), (7, 3), (20, 4), (31, 3), (32, 3)])
+def test_forward_and_score_other_class_counts(classes, c_in):
+    """the Final conv runs two classes per packed FMA: odd / even / minimal / maximal class counts (and 1- and
+    4-channel inputs) must still give bit-exact logits and labels and the oracle's scores"""
+    from helpers import make_model
+    net, P = make_model(classes, c_in, seed=5)
+    x = frames([60, 61], 16, 24, c_in)
+    got, _ = _check_forward(net, P, x, "K=%d" % classes)
+    for m in ("entropy", "margin"):
+        scores, extra = net.score(dev(x), m, return_label=True, return_confidence=True)
+        want_mean, want_conf, want_label, _ = orc.score_images(P, x, m)
+        report_diff("K=%d %s label" % (classes, m), extra["label"].cpu().numpy(), want_label)
+        report_diff("K=%d %s conf" % (classes, m), extra["confidence"].cpu().numpy(), want_conf, exact=False, atol=TOL)
+        report_diff("K=%d %s mean" % (classes, m), scores.cpu().numpy(), want_mean, exact=False, atol=1e-6)
+
+
 def test_fused_score_equals_unfused_path(enet_c3k19):
     """the fused Final+score kernel and (logits -> stand-alone score kernel) agree"""
     net, _ = enet_c3k19

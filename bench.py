@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--classes", type=int, default=19)
     ap.add_argument("--channels", type=int, default=3)
     ap.add_argument("--measure", default="entropy")
+    ap.add_argument("--input-dtype", choices=["f32", "u8"], default="f32",
+                    help="resident frames: float32 in [0,1] (the reference's model input) or the decoded uint8 "
+                         "frames, converted inside the Initial kernel (same bits out)")
     ap.add_argument("--resident-gib", type=float, default=96.0,
                     help="cap on device memory used for resident input frames (wraps beyond it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -125,14 +128,15 @@ def main():
     positions = al.shard_positions(POOL, rank, world)
     positions = positions[positions >= 0]
     n_batches_shard = (len(positions) + bs - 1) // bs
-    bytes_per_batch = bs * h * w * c * 4
+    in_dtype = torch.uint8 if args.input_dtype == "u8" else torch.float32
+    bytes_per_batch = bs * h * w * c * (1 if args.input_dtype == "u8" else 4)
     max_resident = max(1, int(args.resident_gib * 2 ** 30 // bytes_per_batch))
     need = min(args.steps + args.warmup, n_batches_shard)
     n_resident = min(need, max_resident)
     batches = []
     for b in range(n_resident):
         ids = positions[b * bs:(b + 1) * bs]
-        buf = torch.empty((len(ids), h, w, c), dtype=torch.float32, device=dev)
+        buf = torch.empty((len(ids), h, w, c), dtype=in_dtype, device=dev)
         # strided shard: frame ids are not consecutive when world > 1 -> one generator call per frame
         if world == 1:
             syn.synth_frames_device(int(ids[0]), len(ids), h, w, c, out=buf)
@@ -197,8 +201,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: ENet pool of %d synthetic %dx%dx%d frames, %s acquisition, "
-                                   "batch %d, K=%d, top-%d select" % (POOL, h, w, c, args.measure, bs,
-                                                                      args.classes, TOP_K),
+                                   "batch %d, K=%d, top-%d select%s" % (POOL, h, w, c, args.measure, bs, args.classes, TOP_K,
+                                                                        ", uint8 resident frames" if args.input_dtype == "u8" else ""),
                        "frames_scored": int(total_frames), "resident_batches_per_rank": n_resident,
                        "sharding": "strided pool shard per rank, one all-gather of (index, score)"},
         }

@@ -76,6 +76,16 @@ int ssal_enet_score_nhwc(ssal_enet *net, const float *x_dev, int n, int h, int w
                          float threshold, double *scores_dev, uint8_t *label_dev, uint8_t *mask_dev,
                          float *conf_dev, void *ws_dev, int64_t ws_bytes, void *stream);
 
+/* The same two entry points on the DECODED frame: x_dev [n,h,w,c_in] uint8.  The reference converts right after
+ * decoding, `tf.image.convert_image_dtype(image, tf.float32)` = u8 * float32(1/255) (tensortools/input.py:289-290);
+ * here the Initial block does that conversion on the fly: identical bits out, a quarter of the bytes over PCIe
+ * and into the first kernel. */
+int ssal_enet_forward_nhwc_u8(ssal_enet *net, const uint8_t *x_dev, int n, int h, int w,
+                              float *logits_dev, void *ws_dev, int64_t ws_bytes, void *stream);
+int ssal_enet_score_nhwc_u8(ssal_enet *net, const uint8_t *x_dev, int n, int h, int w, int measure,
+                            float threshold, double *scores_dev, uint8_t *label_dev, uint8_t *mask_dev,
+                            float *conf_dev, void *ws_dev, int64_t ws_bytes, void *stream);
+
 /* Byte offsets into the workspace of the last forward/score call of the tensors behind
  * ENet.endpoint_outputs (models/enet/enet.py:311-318): offs[0] bottleneck5_1 [n,h/2,w/2,16],
  * offs[1] bottleneck4_2 [n,h/4,w/4,64], offs[2] bottleneck3_8 [n,h/8,w/8,128]. */
@@ -144,6 +154,9 @@ int ssal_resize_bilinear(const float *x_dev, int n, int h, int w, int c, int oh,
  * (tensortools/input.py:289-290 convert_image_dtype).  Host twin: synthetic.synth_frames_u8(). */
 int ssal_synth_frames_nhwc(uint64_t seed, int64_t first_frame, int count, int h, int w, int c,
                            float *out_dev, void *stream);
+/* the same frames before the conversion: out_dev [count,h,w,c] uint8 */
+int ssal_synth_frames_nhwc_u8(uint64_t seed, int64_t first_frame, int count, int h, int w, int c,
+                              uint8_t *out_dev, void *stream);
 
 /* Kernel-family switch for A/B measurements and cross-checks (no reference counterpart):
  * 1 = MFMA-fused bottleneck kernels on the shapes they support (default), 0 = generic kernels

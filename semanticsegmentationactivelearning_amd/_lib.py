@@ -32,6 +32,8 @@ PROTOTYPES = {
     "ssal_enet_workspace_bytes": (_i64, [_vp, _i, _i, _i]),
     "ssal_enet_forward_nhwc": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i64, _vp]),
     "ssal_enet_score_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "ssal_enet_forward_nhwc_u8": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i64, _vp]),
+    "ssal_enet_score_nhwc_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "ssal_enet_endpoint_offsets": (_i, [_vp, _i, _i, _i, _c.POINTER(_i64)]),
     "ssal_enet_run_layer": (_i, [_vp, _c.c_char_p, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
     "ssal_enet_layer_workspace_bytes": (_i64, [_vp, _c.c_char_p, _i, _i, _i]),
@@ -47,6 +49,7 @@ PROTOTYPES = {
     "ssal_conv2d_transpose_3x3_s2": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "ssal_resize_bilinear": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ssal_synth_frames_nhwc": (_i, [_c.c_uint64, _i64, _i, _i, _i, _i, _vp, _vp]),
+    "ssal_synth_frames_nhwc_u8": (_i, [_c.c_uint64, _i64, _i, _i, _i, _i, _vp, _vp]),
     "ssal_set_kernel_family": (_i, [_i]),
     "ssal_debug_probe": (_i, [_vp, _vp]),
     "ssal_debug_mfma_peak": (_i, [_i, _i, _i, _vp, _vp]),
@@ -166,6 +169,20 @@ def as_device_f32(x, device=None):
         raise ValueError("expected a numpy array or torch tensor")
     if x.dtype != torch.float32:
         x = x.float()
+    if not x.is_cuda:
+        x = x.cuda(device) if device is not None else x.cuda()
+    return x.contiguous()
+
+
+def as_device_image(x, device=None):
+    """model input: uint8 stays uint8 (the decoded frame; the Initial block converts it on the fly exactly like
+    tf.image.convert_image_dtype), everything else becomes float32; contiguous, on the current GPU."""
+    torch = require_gpu()
+    is_u8 = (isinstance(x, np.ndarray) and x.dtype == np.uint8) or (isinstance(x, torch.Tensor) and x.dtype == torch.uint8)
+    if not is_u8:
+        return as_device_f32(x, device)
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x))
     if not x.is_cuda:
         x = x.cuda(device) if device is not None else x.cuda()
     return x.contiguous()

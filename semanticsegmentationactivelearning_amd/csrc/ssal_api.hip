@@ -673,11 +673,11 @@ int check_dims(const ssal_enet *net, int n, int h, int w)
 }
 
 // runs Initial .. Bottleneck5_1; returns the 16-channel half-resolution tensor feeding Final
-hipError_t run_trunk(const ssal_enet *net, const float *x, int n, int h, int w, NetWorkspace &W,
+hipError_t run_trunk(const ssal_enet *net, const void *x, bool x_is_u8, int n, int h, int w, NetWorkspace &W,
                      const float **trunk_out, hipStream_t s)
 {
     const std::vector<DevLayer> &L = net->layers;
-    HIP_RET(launch_initial(x, n, h, w, net->c_in, L[0].w, L[0].scale, L[0].shift, L[0].alpha, W.a0, s));
+    HIP_RET(launch_initial(x, x_is_u8, n, h, w, net->c_in, L[0].w, L[0].scale, L[0].shift, L[0].alpha, W.a0, s));
     int li = 1;
     // stage 1
     HIP_RET(run_down(L[li++], W.a0, n, h / 2, w / 2, W.s1a, W.code1, W.T, s));
@@ -715,8 +715,8 @@ SSAL_API int64_t ssal_enet_workspace_bytes(const ssal_enet *net, int n, int h, i
     return W.bytes + 256;
 }
 
-SSAL_API int ssal_enet_forward_nhwc(ssal_enet *net, const float *x_dev, int n, int h, int w,
-                                    float *logits_dev, void *ws_dev, int64_t ws_bytes, void *stream)
+static int forward_any(ssal_enet *net, const void *x_dev, bool x_is_u8, int n, int h, int w, float *logits_dev,
+                       void *ws_dev, int64_t ws_bytes, void *stream)
 {
     int rc = check_dims(net, n, h, w);
     if (rc) return rc;
@@ -726,7 +726,7 @@ SSAL_API int ssal_enet_forward_nhwc(ssal_enet *net, const float *x_dev, int n, i
                            (long long)W.bytes, (long long)ws_bytes);
     hipStream_t s = (hipStream_t)stream;
     const float *trunk = nullptr;
-    HIP_TRY(run_trunk(net, x_dev, n, h, w, W, &trunk, s));
+    HIP_TRY(run_trunk(net, x_dev, x_is_u8, n, h, w, W, &trunk, s));
     // logits only: the score outputs of the fused kernel go to the scratch partial buffer
     HIP_TRY(launch_final_score(trunk, n, h / 2, w / 2, net->layers[kNumLayers - 1].w, net->classes,
                                logits_dev, SSAL_MEASURE_CONFIDENCE, 0.0f, W.partial, nullptr,
@@ -734,10 +734,21 @@ SSAL_API int ssal_enet_forward_nhwc(ssal_enet *net, const float *x_dev, int n, i
     return SSAL_OK;
 }
 
-SSAL_API int ssal_enet_score_nhwc(ssal_enet *net, const float *x_dev, int n, int h, int w,
-                                  int measure, float threshold, double *scores_dev,
-                                  uint8_t *label_dev, uint8_t *mask_dev, float *conf_dev,
-                                  void *ws_dev, int64_t ws_bytes, void *stream)
+SSAL_API int ssal_enet_forward_nhwc(ssal_enet *net, const float *x_dev, int n, int h, int w,
+                                    float *logits_dev, void *ws_dev, int64_t ws_bytes, void *stream)
+{
+    return forward_any(net, x_dev, false, n, h, w, logits_dev, ws_dev, ws_bytes, stream);
+}
+
+SSAL_API int ssal_enet_forward_nhwc_u8(ssal_enet *net, const uint8_t *x_dev, int n, int h, int w,
+                                       float *logits_dev, void *ws_dev, int64_t ws_bytes, void *stream)
+{
+    return forward_any(net, x_dev, true, n, h, w, logits_dev, ws_dev, ws_bytes, stream);
+}
+
+static int score_any(ssal_enet *net, const void *x_dev, bool x_is_u8, int n, int h, int w, int measure,
+                     float threshold, double *scores_dev, uint8_t *label_dev, uint8_t *mask_dev, float *conf_dev,
+                     void *ws_dev, int64_t ws_bytes, void *stream)
 {
     int rc = check_dims(net, n, h, w);
     if (rc) return rc;
@@ -749,13 +760,31 @@ SSAL_API int ssal_enet_score_nhwc(ssal_enet *net, const float *x_dev, int n, int
                            (long long)W.bytes, (long long)ws_bytes);
     hipStream_t s = (hipStream_t)stream;
     const float *trunk = nullptr;
-    HIP_TRY(run_trunk(net, x_dev, n, h, w, W, &trunk, s));
+    HIP_TRY(run_trunk(net, x_dev, x_is_u8, n, h, w, W, &trunk, s));
     HIP_TRY(launch_final_score(trunk, n, h / 2, w / 2, net->layers[kNumLayers - 1].w, net->classes,
                                nullptr, measure, threshold, W.partial, label_dev, mask_dev,
                                conf_dev, s));
     HIP_TRY(launch_reduce_mean(W.partial, n, final_score_blocks(h / 2, w / 2), (double)h * (double)w,
                                scores_dev, s));
     return SSAL_OK;
+}
+
+SSAL_API int ssal_enet_score_nhwc(ssal_enet *net, const float *x_dev, int n, int h, int w,
+                                  int measure, float threshold, double *scores_dev,
+                                  uint8_t *label_dev, uint8_t *mask_dev, float *conf_dev,
+                                  void *ws_dev, int64_t ws_bytes, void *stream)
+{
+    return score_any(net, x_dev, false, n, h, w, measure, threshold, scores_dev, label_dev, mask_dev, conf_dev,
+                     ws_dev, ws_bytes, stream);
+}
+
+SSAL_API int ssal_enet_score_nhwc_u8(ssal_enet *net, const uint8_t *x_dev, int n, int h, int w,
+                                     int measure, float threshold, double *scores_dev,
+                                     uint8_t *label_dev, uint8_t *mask_dev, float *conf_dev,
+                                     void *ws_dev, int64_t ws_bytes, void *stream)
+{
+    return score_any(net, x_dev, true, n, h, w, measure, threshold, scores_dev, label_dev, mask_dev, conf_dev,
+                     ws_dev, ws_bytes, stream);
 }
 
 // byte offsets (into the workspace passed to forward/score) of the tensors behind
@@ -828,7 +857,7 @@ SSAL_API int ssal_enet_run_layer(ssal_enet *net, const char *layer, const float 
     T.t3 = b.take<float>(sz[3]);
     switch (L.kind) {
     case K_INITIAL:
-        HIP_TRY(launch_initial(x_dev, n, h, w, net->c_in, L.w, L.scale, L.shift, L.alpha, y_dev, s));
+        HIP_TRY(launch_initial(x_dev, false, n, h, w, net->c_in, L.w, L.scale, L.shift, L.alpha, y_dev, s));
         break;
     case K_REGULAR:
         HIP_TRY(run_regular(L, x_dev, n, h, w, y_dev, T, s));
@@ -1023,7 +1052,17 @@ SSAL_API int ssal_synth_frames_nhwc(uint64_t seed, int64_t first_frame, int coun
     if (!out_dev) return fail(SSAL_EINVAL, "NULL device pointer");
     if (count <= 0 || h <= 0 || w <= 0 || c <= 0 || h % 8 || w % 8)
         return fail(SSAL_EINVAL, "bad dims count=%d h=%d w=%d c=%d (H, W must be divisible by 8)", count, h, w, c);
-    HIP_TRY(launch_synth_frames(seed, first_frame, count, h, w, c, out_dev, (hipStream_t)stream));
+    HIP_TRY(launch_synth_frames(seed, first_frame, count, h, w, c, out_dev, false, (hipStream_t)stream));
+    return SSAL_OK;
+}
+
+SSAL_API int ssal_synth_frames_nhwc_u8(uint64_t seed, int64_t first_frame, int count, int h, int w,
+                                       int c, uint8_t *out_dev, void *stream)
+{
+    if (!out_dev) return fail(SSAL_EINVAL, "NULL device pointer");
+    if (count <= 0 || h <= 0 || w <= 0 || c <= 0 || h % 8 || w % 8)
+        return fail(SSAL_EINVAL, "bad dims count=%d h=%d w=%d c=%d (H, W must be divisible by 8)", count, h, w, c);
+    HIP_TRY(launch_synth_frames(seed, first_frame, count, h, w, c, out_dev, true, (hipStream_t)stream));
     return SSAL_OK;
 }
 

@@ -39,7 +39,7 @@ hipError_t launch_convT(const float *x, int N, int H, int W, int Cin, const floa
                         hipStream_t s);
 
 // Initial block (enet_modules.py:190-224): concat[conv3x3 s2, maxpool2x2] -> BN -> PReLU, 16 channels out.
-hipError_t launch_initial(const float *x, int N, int H, int W, int Cin, const float *w,
+hipError_t launch_initial(const void *x, bool x_is_u8, int N, int H, int W, int Cin, const float *w,
                           const float *scale, const float *shift, const float *alpha, float *y,
                           hipStream_t s);
 
@@ -123,6 +123,6 @@ hipError_t launch_bn_fold(const float *mean, const float *var, const float *gamm
 hipError_t launch_resize_bilinear(const float *x, int N, int H, int W, int C, int OH, int OW,
                                   float *y, hipStream_t s);
 hipError_t launch_synth_frames(uint64_t seed, int64_t first, int count, int H, int W, int C,
-                               float *out, hipStream_t s);
+                               void *out, bool out_is_u8, hipStream_t s);
 
 }  // namespace ssal

@@ -22,9 +22,15 @@ __device__ __forceinline__ float prelu_f(float v, float a) { return v >= 0.0f ? 
 // Initial block: concat[ conv3x3 s2 SAME (Cin -> 16-Cin), maxpool2x2 s2 (Cin) ] -> BN(16) -> PReLU(16)
 // (enet_modules.py:190-224; concat order conv first :214-215).  SAME on even H,W: pad (0 before, 1 after).
 // One thread per output pixel; kernel weights are wave-uniform (scalar loads).
+// TX = float: the reference's tensor (train_image_raw, float32 in [0,1]); TX = uint8_t: the decoded frame,
+// converted on the fly exactly as tf.image.convert_image_dtype does (input.py:289-290): x = u8 * f32(1/255)
+// -- a quarter of the bytes over PCIe and into this kernel, identical bits out.
 // ------------------------------------------------------------------------------------------------
-template <int CIN>
-__global__ __launch_bounds__(256) void k_initial(const float *__restrict__ x,
+__device__ __forceinline__ float to_unit(float v) { return v; }
+__device__ __forceinline__ float to_unit(uint8_t v) { return (float)v * (1.0f / 255.0f); }
+
+template <int CIN, typename TX>
+__global__ __launch_bounds__(256) void k_initial(const TX *__restrict__ x,
                                                  const float *__restrict__ w,
                                                  const float *__restrict__ scale,
                                                  const float *__restrict__ shift,
@@ -53,10 +59,10 @@ __global__ __launch_bounds__(256) void k_initial(const float *__restrict__ x,
             for (int kw = 0; kw < 3; ++kw) {
                 const int ix = 2 * ox + kw;
                 if (ix >= W) continue;
-                const float *xp = x + (((long)n * H + iy) * W + ix) * CIN;
+                const TX *xp = x + (((long)n * H + iy) * W + ix) * CIN;
                 float xv[CIN];
 #pragma unroll
-                for (int ci = 0; ci < CIN; ++ci) xv[ci] = xp[ci];
+                for (int ci = 0; ci < CIN; ++ci) xv[ci] = to_unit(xp[ci]);
 #pragma unroll
                 for (int ci = 0; ci < CIN; ++ci) {
                     const float *wr = w + ((kh * 3 + kw) * CIN + ci) * CC;
@@ -84,22 +90,31 @@ __global__ __launch_bounds__(256) void k_initial(const float *__restrict__ x,
     }
 }
 
-hipError_t launch_initial(const float *x, int N, int H, int W, int Cin, const float *w,
-                          const float *scale, const float *shift, const float *alpha, float *y,
-                          hipStream_t s)
+template <typename TX>
+static hipError_t launch_initial_t(const TX *x, int N, int H, int W, int Cin, const float *w, const float *scale,
+                                   const float *shift, const float *alpha, float *y, hipStream_t s)
 {
     const long total = (long)N * (H / 2) * (W / 2);
     const int grid = cdiv(total, 256);
-    ProfScope prof("k_initial", 2.0 * total * 9 * Cin * (16 - Cin), 4.0 * ((double)N * H * W * Cin + total * 16.0), s);
+    ProfScope prof("k_initial", 2.0 * total * 9 * Cin * (16 - Cin),
+                   (double)sizeof(TX) * N * H * W * Cin + 4.0 * total * 16.0, s);
     if (Cin == 3)
-        hipLaunchKernelGGL(k_initial<3>, dim3(grid), dim3(256), 0, s, x, w, scale, shift, alpha, y, N, H, W);
+        hipLaunchKernelGGL((k_initial<3, TX>), dim3(grid), dim3(256), 0, s, x, w, scale, shift, alpha, y, N, H, W);
     else if (Cin == 4)
-        hipLaunchKernelGGL(k_initial<4>, dim3(grid), dim3(256), 0, s, x, w, scale, shift, alpha, y, N, H, W);
+        hipLaunchKernelGGL((k_initial<4, TX>), dim3(grid), dim3(256), 0, s, x, w, scale, shift, alpha, y, N, H, W);
     else if (Cin == 1)
-        hipLaunchKernelGGL(k_initial<1>, dim3(grid), dim3(256), 0, s, x, w, scale, shift, alpha, y, N, H, W);
+        hipLaunchKernelGGL((k_initial<1, TX>), dim3(grid), dim3(256), 0, s, x, w, scale, shift, alpha, y, N, H, W);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();
+}
+
+hipError_t launch_initial(const void *x, bool x_is_u8, int N, int H, int W, int Cin, const float *w,
+                          const float *scale, const float *shift, const float *alpha, float *y,
+                          hipStream_t s)
+{
+    return x_is_u8 ? launch_initial_t((const uint8_t *)x, N, H, W, Cin, w, scale, shift, alpha, y, s)
+                   : launch_initial_t((const float *)x, N, H, W, Cin, w, scale, shift, alpha, y, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -971,8 +986,9 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t z)
     return z ^ (z >> 31);
 }
 
+template <typename TO>
 __global__ __launch_bounds__(256) void k_synth_frames(uint64_t seed, long first, int count, int H,
-                                                      int W, int C, float *__restrict__ out)
+                                                      int W, int C, TO *__restrict__ out)
 {
     const long per = (long)H * W * C;
     const long total = per * count;
@@ -992,18 +1008,23 @@ __global__ __launch_bounds__(256) void k_synth_frames(uint64_t seed, long first,
         float v = (float)(coarse + fine) * bright;
         v = fminf(fmaxf(v, 0.0f), 255.0f);
         const int u8 = (int)v;
-        out[o] = (float)u8 * (1.0f / 255.0f);
+        if (sizeof(TO) == 1) out[o] = (TO)u8;                          // the decoded frame
+        else out[o] = (TO)((float)u8 * (1.0f / 255.0f));                // after convert_image_dtype
     }
 }
 
 hipError_t launch_synth_frames(uint64_t seed, int64_t first, int count, int H, int W, int C,
-                               float *out, hipStream_t s)
+                               void *out, bool out_is_u8, hipStream_t s)
 {
     const long total = (long)H * W * C * count;
     int grid = cdiv(total, 256);
     if (grid > 262144) grid = 262144;
-    hipLaunchKernelGGL(k_synth_frames, dim3(grid), dim3(256), 0, s, seed, (long)first, count, H, W,
-                       C, out);
+    if (out_is_u8)
+        hipLaunchKernelGGL(k_synth_frames<uint8_t>, dim3(grid), dim3(256), 0, s, seed, (long)first, count, H, W, C,
+                           (uint8_t *)out);
+    else
+        hipLaunchKernelGGL(k_synth_frames<float>, dim3(grid), dim3(256), 0, s, seed, (long)first, count, H, W, C,
+                           (float *)out);
     return hipGetLastError();
 }
 

@@ -147,7 +147,7 @@ class ENet:
             raise NotImplementedError(
                 "training=True (spatial dropout + batch statistics) is outside the MI355X "
                 "scoring path; call with training=False")
-        x = _lib.as_device_f32(inputs)
+        x = _lib.as_device_image(inputs)  # float32 in [0,1] (the reference's tensor) or the uint8 decoded frame
         if x.dim() != 4:
             raise ValueError("inputs must be NHWC rank-4 (got shape %s)" % (tuple(x.shape),))
         if not self.built:
@@ -173,8 +173,9 @@ class ENet:
                 raise ValueError("bad input dims %s" % (tuple(x.shape),))
             ws = self._workspace(nbytes, x.device)
             logits = torch.empty((n, h, w, self.classes), dtype=torch.float32, device=x.device)
-            _lib.check(L.ssal_enet_forward_nhwc(handle, _lib.dev_ptr(x), n, h, w, _lib.dev_ptr(logits),
-                                                _lib.dev_ptr(ws), ws.numel(), _lib.stream_ptr()))
+            fwd = L.ssal_enet_forward_nhwc_u8 if x.dtype == torch.uint8 else L.ssal_enet_forward_nhwc
+            _lib.check(fwd(handle, _lib.dev_ptr(x), n, h, w, _lib.dev_ptr(logits),
+                           _lib.dev_ptr(ws), ws.numel(), _lib.stream_ptr()))
             self._record_endpoints(logits, ws, n, h, w)
         self.outputs.append(logits)
         return logits
@@ -217,7 +218,8 @@ class ENet:
             label = torch.empty((n, h, w), dtype=torch.uint8, device=x.device) if return_label else None
             mask = torch.empty((n, h, w), dtype=torch.uint8, device=x.device) if return_mask else None
             conf = torch.empty((n, h, w), dtype=torch.float32, device=x.device) if return_confidence else None
-            _lib.check(L.ssal_enet_score_nhwc(
+            score = L.ssal_enet_score_nhwc_u8 if x.dtype == torch.uint8 else L.ssal_enet_score_nhwc
+            _lib.check(score(
                 handle, _lib.dev_ptr(x), n, h, w, _lib.MEASURES[measure], float(threshold),
                 _lib.dev_ptr(scores, torch.float64, "scores"), _lib.dev_ptr(label), _lib.dev_ptr(mask),
                 _lib.dev_ptr(conf), _lib.dev_ptr(ws), ws.numel(), _lib.stream_ptr()))

@@ -60,18 +60,21 @@ def synth_frames_f32(frames, h, w, c, seed=0):
     return np.stack([u8_to_f32(synth_frame_u8(int(f), h, w, c, seed)) for f in frames])
 
 
-def synth_frames_device(first_frame, count, h, w, c, seed=0, out=None, device=None):
-    """Generate ``count`` consecutive frames directly in HBM (float32 NHWC torch tensor)."""
+def synth_frames_device(first_frame, count, h, w, c, seed=0, out=None, device=None, dtype=None):
+    """Generate ``count`` consecutive frames directly in HBM: float32 NHWC (= uint8 * 1/255, the default) or,
+    with ``dtype=torch.uint8`` / a uint8 ``out``, the decoded uint8 frames themselves."""
     torch = _lib.require_gpu()
     if out is None:
-        out = torch.empty((count, h, w, c), dtype=torch.float32,
+        out = torch.empty((count, h, w, c), dtype=dtype if dtype is not None else torch.float32,
                           device=device if device is not None else torch.device("cuda", torch.cuda.current_device()))
     if tuple(out.shape) != (count, h, w, c):
         raise ValueError("out has shape %s, expected %s" % (tuple(out.shape), (count, h, w, c)))
+    if out.dtype not in (torch.float32, torch.uint8):
+        raise ValueError("frames are float32 or uint8 (got %s)" % out.dtype)
     with torch.cuda.device(out.device):
-        _lib.check(_lib.lib().ssal_synth_frames_nhwc(int(seed), int(first_frame), count, h, w, c,
-                                                     _lib.dev_ptr(out, torch.float32, "out"),
-                                                     _lib.stream_ptr()))
+        gen = _lib.lib().ssal_synth_frames_nhwc_u8 if out.dtype == torch.uint8 else _lib.lib().ssal_synth_frames_nhwc
+        _lib.check(gen(int(seed), int(first_frame), count, h, w, c, _lib.dev_ptr(out, out.dtype, "out"),
+                       _lib.stream_ptr()))
     return out
 
 

@@ -44,6 +44,23 @@ def test_synth_frames_device_equals_host(h, w, c, first, count):
     report_diff("frames", got, want)
 
 
+def test_uint8_frames_same_bits_as_float32_frames(enet_c3k19, enet_c4k6):
+    """the decoded uint8 frame goes straight into the Initial block (converted on the fly like
+    tf.image.convert_image_dtype, input.py:289-290): logits, labels and scores must equal the float32 path"""
+    u8 = syn.synth_frames_device(70, 3, 64, 96, 3, dtype=torch.uint8)
+    host = np.stack([syn.synth_frame_u8(f, 64, 96, 3) for f in (70, 71, 72)])
+    assert u8.dtype == torch.uint8 and (u8.cpu().numpy() == host).all()
+    for (net, P), c in ((enet_c3k19, 3), (enet_c4k6, 4)):
+        xu = syn.synth_frames_device(70, 3, 64, 96, c, dtype=torch.uint8)
+        xf = syn.synth_frames_device(70, 3, 64, 96, c)
+        assert torch.equal(net(xu, training=False), net(xf, training=False))
+        su, eu = net.score(xu, "entropy", return_label=True, return_confidence=True)
+        sf, ef = net.score(xf, "entropy", return_label=True, return_confidence=True)
+        assert torch.equal(su, sf) and torch.equal(eu["label"], ef["label"]) and torch.equal(eu["confidence"], ef["confidence"])
+        # numpy uint8 input takes the same route
+        assert torch.equal(net.score(xu.cpu().numpy(), "margin"), net.score(xf, "margin"))
+
+
 # ---- stand-alone operators -----------------------------------------------------------------------
 @pytest.mark.parametrize("kh,kw,stride,dil,h,w,cin,cout", [
     (1, 1, 1, 1, 16, 24, 64, 16), (1, 1, 1, 1, 9, 7, 16, 64), (1, 1, 1, 1, 8, 8, 32, 128), (1, 1, 1, 1, 8, 8, 128, 32),

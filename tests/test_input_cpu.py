@@ -98,6 +98,19 @@ def test_eval_path_center_crop_labels_and_partial_batch(tmp_path):
         stage.get_output()
 
 
+def test_uint8_image_option_hands_out_the_decoded_frame(tmp_path):
+    write_pool(str(tmp_path), 3, 40, 56)
+    stage = InputStage(input_shape=[32, 48], image_dtype=np.uint8)
+    stage.add_dataset("val", str(tmp_path), batch_size=3)
+    stage.init_iterator("val")
+    img, lab, mask = stage.get_output()
+    assert img.dtype == np.uint8 and img.shape == (3, 32, 48, 3)
+    assert (img[0] == syn.synth_frame_u8(0, 40, 56, 3)[4:36, 4:52]).all()
+    assert (syn.u8_to_f32(img[0]) == syn.u8_to_f32(syn.synth_frame_u8(0, 40, 56, 3))[4:36, 4:52]).all()
+    with pytest.raises(ValueError):
+        InputStage(image_dtype=np.float64)
+
+
 def test_rank_path_aux_channels_and_capsule_feed(tmp_path):
     files = write_pool(str(tmp_path), 6, 32, 32, with_label=False)
     cap = NumpyCapsule(shuffle=True, seed=0)

@@ -110,17 +110,63 @@ def all_gather_scores(local_index, local_score, group=None):
     return gathered[:, 0].to(torch.int64), gathered[:, 1]
 
 
+def prefetch_to_device(batches, depth=2):
+    """Host batches -> device batches, copied ``depth`` batches ahead on a side HIP stream, so that the
+    host-to-device copy of batch i+1 overlaps the kernels of batch i (the reference gets
+    the same effect from ``tf.data`` prefetching, ``tensortools/input.py:195``).  ``batches`` yields
+    ``(images, example_indices)`` with images as numpy / CPU-torch arrays (uint8 frames or float32) or tensors
+    already on the GPU (passed through)."""
+    import collections
+    torch = _lib.require_gpu()
+    copy_stream = torch.cuda.Stream()
+    queue = collections.deque()
+
+    def stage(item):
+        images, indices = item
+        if isinstance(images, torch.Tensor) and images.is_cuda:
+            return images, indices, None, None
+        host = images if isinstance(images, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(images))
+        host = host.contiguous()
+        # The copy runs on the side stream, i.e. NOT behind the kernels of the batches already enqueued on the
+        # compute stream.  Pinned sources are copied asynchronously; pageable ones block the host for the copy
+        # (the runtime stages them through its own pinned buffers) while the GPU keeps computing.  Pinning
+        # per batch here would cost more than it saves (page-locking 50-200 MB takes milliseconds).
+        with torch.cuda.stream(copy_stream):
+            dev = host.cuda(non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(copy_stream)
+        return dev, indices, done, host  # the host buffer must outlive the copy
+
+    def release(entry):
+        dev, indices, done, _pinned = entry
+        if done is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(done)
+            dev.record_stream(cur)  # allocated on the copy stream, consumed on this one
+        return dev, indices
+
+    for item in batches:
+        queue.append(stage(item))
+        if len(queue) > depth:
+            yield release(queue.popleft())
+    while queue:
+        yield release(queue.popleft())
+
+
 def rank_confidence(net, batches, num_examples, unlabelled, selection_size, measure="entropy",
-                    group=None):
+                    group=None, prefetch=0):
     """Mirror of ``rank_confidence()`` (reference :682-715).
 
-    ``batches`` yields ``(images NHWC float32, example_indices)``; on a multi-GPU job each rank
-    passes only its own shard.  Returns ``(low_conf_examples, unlabelled_confidence)``: the ids (into
+    ``batches`` yields ``(images NHWC float32 or uint8, example_indices)``; on a multi-GPU job each rank
+    passes only its own shard.  ``prefetch`` > 0 copies host batches that many batches ahead on a side
+    stream (``prefetch_to_device``).  Returns ``(low_conf_examples, unlabelled_confidence)``: the ids (into
     the full example list) of the ``selection_size`` least confident unlabelled examples and the
     float32 confidence of every unlabelled example (the reference feeds it to a histogram summary,
     :781-784)."""
     torch = _lib.require_gpu()
     idx_chunks, score_chunks = [], []
+    if prefetch > 0:
+        batches = prefetch_to_device(batches, depth=prefetch)
     for images, indices in batches:
         s = net.score(images, measure=measure)  # [n] float64 on device, stream-ordered
         score_chunks.append(s)

@@ -66,14 +66,25 @@ class InputStage:
     """Holds named datasets and ONE re-initialisable iterator shared by them (reference :34-233)."""
 
     def __init__(self, input_shape=[512, 512], scope="Dataset", modalities=(), seed=None, workers=None,
-                 image_dtype=np.float32):
+                 image_dtype=np.float32, pin_memory=False, pin_buffers=6):
         """``image_dtype=np.uint8`` (not in the reference): hand out the undistorted image as the decoded uint8
         frame instead of float32 in [0,1]; ``ENet.score`` converts it on the GPU (same bits, a quarter of the
-        host-to-device bytes)."""
+        host-to-device bytes).
+
+        ``pin_memory=True`` (not in the reference; needs the GPU runtime): the image batch is assembled directly
+        in page-locked memory and handed out as a CPU torch tensor, so that ``rank_confidence(..., prefetch=2)``
+        copies it asynchronously while the previous batch is being scored.  The batches are views of a ring of
+        ``pin_buffers`` buffers: a batch stays valid until ``pin_buffers - 1`` further batches have been drawn."""
         self.logger = logging.getLogger(__name__)
         if np.dtype(image_dtype) not in (np.dtype(np.float32), np.dtype(np.uint8)):
             raise ValueError("image_dtype must be float32 or uint8")
         self.image_dtype = np.dtype(image_dtype)
+        self.pin_memory = bool(pin_memory)
+        self.pin_buffers = int(pin_buffers)
+        if self.pin_memory and self.pin_buffers < 2:
+            raise ValueError("pin_buffers must be >= 2")
+        self._pinned = []  # ring of page-locked image batch buffers (allocated lazily, reused)
+        self._pin_pos = 0
         if len(input_shape) == 3:
             self.shape = list(input_shape)
         elif len(input_shape) == 2:
@@ -162,9 +173,29 @@ class InputStage:
                 items = [futures.pop(0).result() for _ in range(n)]
                 submit_until(window)
                 cols = list(zip(*items))
-                batch = tuple(np.stack(c) for c in cols) + tuple(a[start:start + n] for a in aux)
+                first = self._stack_pinned(cols[0]) if self.pin_memory else np.stack(cols[0])
+                batch = (first,) + tuple(np.stack(c) for c in cols[1:]) + tuple(a[start:start + n] for a in aux)
                 start += n
                 yield batch
+
+    def _stack_pinned(self, images):
+        """np.stack(images) written into the next buffer of the page-locked ring -> CPU torch tensor"""
+        import torch
+        shape = (len(images),) + tuple(images[0].shape)
+        dtype = torch.uint8 if images[0].dtype == np.uint8 else torch.float32
+        need = int(np.prod(shape))
+        if len(self._pinned) < self.pin_buffers:
+            self._pinned.append(torch.empty(need, dtype=dtype, pin_memory=True))
+            buf = self._pinned[-1]
+        else:
+            k = self._pin_pos % self.pin_buffers
+            if self._pinned[k].numel() < need or self._pinned[k].dtype != dtype:
+                self._pinned[k] = torch.empty(need, dtype=dtype, pin_memory=True)
+            buf = self._pinned[k]
+        self._pin_pos += 1
+        out = buf[:need].view(shape)
+        np.stack(images, out=out.numpy())
+        return out
 
     # ---- per-example work -------------------------------------------------------------------------
     def _load_one(self, filename, augment, seed):

@@ -534,6 +534,50 @@ def test_rank_confidence_from_tfrecords(enet_c3k19, tmp_path):
     report_diff("unlabelled_confidence", uc, want_uc, exact=False, atol=1e-6)
 
 
+def test_rank_confidence_from_tfrecords_pinned_uint8_prefetch(enet_c3k19, tmp_path):
+    """the production feed: TFRecords -> InputStage(uint8 frames in page-locked batches) -> side-stream copy ->
+    GPU conversion + scoring; must rank exactly like the plain float32 path"""
+    from test_input_cpu import write_pool
+    from semanticsegmentationactivelearning_amd.tensortools import InputStage
+    net, P = enet_c3k19
+    num = 11
+    write_pool(str(tmp_path), num, 64, 64, with_label=False)
+    results = []
+    for kwargs, prefetch in (({}, 0), ({"image_dtype": np.uint8, "pin_memory": True, "pin_buffers": 4}, 2)):
+        stage = InputStage(input_shape=[64, 64], **kwargs)
+        stage.add_dataset("val", str(tmp_path), batch_size=3)
+        stage.init_iterator("val")
+        pos = [0]
+
+        def batches():
+            for image, label, mask in stage:
+                n = len(image)
+                yield image, np.arange(pos[0], pos[0] + n)
+                pos[0] += n
+        results.append(al.rank_confidence(net, batches(), num, np.arange(num), 3, prefetch=prefetch))
+    (low_a, uc_a), (low_b, uc_b) = results
+    assert set(low_a.tolist()) == set(low_b.tolist()) and (uc_a == uc_b).all()
+
+
+def test_rank_confidence_prefetch_and_uint8_host_batches(enet_c3k19):
+    """host batches (uint8 decoded frames) copied ahead on a side stream give the same ranking as device batches"""
+    net, P = enet_c3k19
+    num, bs = 10, 4
+    host = [np.stack([syn.synth_frame_u8(f, 64, 64, 3) for f in range(b, min(b + bs, num))]) for b in range(0, num, bs)]
+
+    def host_batches():
+        for k, x in enumerate(host):
+            yield x, np.arange(k * bs, k * bs + len(x))
+
+    def dev_batches():
+        for k, x in enumerate(host):
+            yield dev(syn.u8_to_f32(x)), np.arange(k * bs, k * bs + len(x))
+    low_a, uc_a = al.rank_confidence(net, dev_batches(), num, np.arange(num), 3)
+    for pf in (1, 2, 5):
+        low_b, uc_b = al.rank_confidence(net, host_batches(), num, np.arange(num), 3, prefetch=pf)
+        assert set(low_a.tolist()) == set(low_b.tolist()) and (uc_a == uc_b).all()
+
+
 # ---- SURVEY 8(f) rows 3 and 4: loss forward value, inference path ------------------------------------
 @pytest.mark.parametrize("weight,ls,k", [(0.0, 0.0, 19), (0.0, 0.05, 19), (1.5, 0.05, 19), (1.02, 0.1, 6)])
 def test_masked_softmax_cross_entropy_forward(weight, ls, k):

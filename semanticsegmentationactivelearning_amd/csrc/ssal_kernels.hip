@@ -55,14 +55,30 @@ __global__ __launch_bounds__(256) void k_initial(const TX *__restrict__ x,
         for (int kh = 0; kh < 3; ++kh) {
             const int iy = 2 * oy + kh;
             if (iy >= H) continue;
+            // the 3 x CIN values of this kernel row are contiguous in memory: fetch them with the widest loads
+            // their alignment allows (float input: element offset 2*ox*CIN is even -> 8-byte aligned)
+            const TX *xrow = x + (((long)n * H + iy) * W + 2 * ox) * CIN;
+            const bool third = 2 * ox + 2 < W;  // SAME padding on even W: the last column has no third pixel
+            float rowv[3 * CIN];
+            if (sizeof(TX) == 4 && (2 * CIN) % 2 == 0) {
+                const float2 *x2 = reinterpret_cast<const float2 *>(xrow);
+#pragma unroll
+                for (int q = 0; q < CIN; ++q) {  // pixels 0 and 1: 2*CIN floats
+                    const float2 v = x2[q];
+                    rowv[2 * q] = v.x; rowv[2 * q + 1] = v.y;
+                }
+#pragma unroll
+                for (int q = 0; q < CIN; ++q) rowv[2 * CIN + q] = third ? to_unit(xrow[2 * CIN + q]) : 0.0f;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 3 * CIN; ++q) rowv[q] = (q < 2 * CIN || third) ? to_unit(xrow[q]) : 0.0f;
+            }
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-                const int ix = 2 * ox + kw;
-                if (ix >= W) continue;
-                const TX *xp = x + (((long)n * H + iy) * W + ix) * CIN;
+                if (kw == 2 && !third) continue;
                 float xv[CIN];
 #pragma unroll
-                for (int ci = 0; ci < CIN; ++ci) xv[ci] = to_unit(xp[ci]);
+                for (int ci = 0; ci < CIN; ++ci) xv[ci] = rowv[kw * CIN + ci];
 #pragma unroll
                 for (int ci = 0; ci < CIN; ++ci) {
                     const float *wr = w + ((kh * 3 + kw) * CIN + ci) * CC;

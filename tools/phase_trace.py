@@ -40,7 +40,10 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("layers", nargs="*", default=["Bottleneck2_1", "Bottleneck1_1"])
     args = ap.parse_args()
-    if args.build_only or not os.path.exists(TRACE_LIB):
+    src_dir = os.path.join(PKG, "csrc")
+    newest_src = max(os.path.getmtime(os.path.join(src_dir, f)) for f in os.listdir(src_dir))
+    stale = os.path.exists(TRACE_LIB) and os.path.getmtime(TRACE_LIB) < newest_src
+    if args.build_only or stale or not os.path.exists(TRACE_LIB):
         build_trace_lib()
         if args.build_only:
             return

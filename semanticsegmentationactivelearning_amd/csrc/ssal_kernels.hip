@@ -399,13 +399,18 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // loads of group g+1 (or of the first group of the NEXT tap, wnext) are issued before the FMAs of group
 // g; sched_barrier pins that order.  (Left alone the compiler hoists whole taps and spills ~1500 SGPRs
 // through v_writelane / v_readlane, doubling the VALU work of this VALU-bound kernel.)
+// Scalar loads return out of order, so the only wait the hardware offers is lgkmcnt(0) = "everything": the
+// explicit wait at the top of every step completes the group about to be used BEFORE the next prefetch is
+// issued (a compiler-placed wait would sit after it and drain the prefetch as well, i.e. expose the full
+// scalar-load latency at every step).  G = input channels per group: the FMAs of one group (10 G
+// instructions for K = 19) are all the cover a prefetch gets, so G = 2 where the SGPR file allows it (the
+// score-only kernel; with the optional outputs' pointers live, 80 buffer SGPRs spill).
 // On entry w0 holds group 0 of this tap; on exit it holds group 0 of wnext (if not NULL).
-template <int K>
+template <int K, int G>
 struct FsTap {
     static constexpr int KP = (K + 1) / 2;           // class pairs
-    static constexpr int G = 1;  // input channels per group (2 was measured: 80 buffer SGPRs crowd out the
-                                 // kernel's pointers -> ~470 lane moves per thread, 6 % slower)
     static constexpr int NG = 16 / G, WN = G * 2 * KP, TS = 16 * 2 * KP;
+    static constexpr int kWaitScalar = 0xC07F;        // s_waitcnt lgkmcnt(0), vmcnt / expcnt untouched
     static __device__ __forceinline__ void load(const float *__restrict__ p, float (&w)[WN])
     {
 #pragma unroll
@@ -429,9 +434,13 @@ struct FsTap {
     {
 #pragma unroll
         for (int g = 0; g < NG; g += 2) {
+            __builtin_amdgcn_s_waitcnt(kWaitScalar);  // w0 (requested one step ago) has arrived
+            __builtin_amdgcn_sched_barrier(0);
             load(wtap + (g + 1) * WN, w1);
             __builtin_amdgcn_sched_barrier(0);
             fma(acc, v, g * G, w0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(kWaitScalar);  // w1 has arrived
             __builtin_amdgcn_sched_barrier(0);
             if (g + 2 < NG) load(wtap + (g + 2) * WN, w0);
             else if (wnext) load(wnext, w0);
@@ -442,7 +451,9 @@ struct FsTap {
     }
 };
 
-template <int K>
+// OUT = false: score only (the ranking pass): logits / label / mask / conf are not touched, which frees the
+// SGPRs their pointers would pin and lets the kernel taps stream two input channels at a time.
+template <int K, bool OUT>
 __global__ __launch_bounds__(256) void k_final_score(const float *__restrict__ x, int N, int H,
                                                      int W, const float *__restrict__ wF,
                                                      float *__restrict__ logits, int measure,
@@ -480,7 +491,7 @@ __global__ __launch_bounds__(256) void k_final_score(const float *__restrict__ x
         }
         const float inv_logK = 1.0f / __logf((float)K);
         const int Wo = 2 * W;
-        typedef FsTap<K> FT;
+        typedef FsTap<K, (!OUT && 2 * ((K + 1) / 2) <= 20) ? 2 : 1> FT;
         constexpr int KP = FT::KP, TS = FT::TS;
         float w0[FT::WN], w1[FT::WN];
         f32x2 acc2[KP];
@@ -494,7 +505,7 @@ __global__ __launch_bounds__(256) void k_final_score(const float *__restrict__ x
             for (int k = 0; k < KP; ++k) acc2[k] = (f32x2){0.0f, 0.0f};
             const int oy = 2 * i + (quad >> 1), ox = 2 * j + (quad & 1);
             const long op = ((long)n * 2 * H + oy) * Wo + ox;
-            if (logits) {
+            if (OUT && logits) {
                 float *lp = logits + op * K;
 #pragma unroll
                 for (int k = 0; k < K; ++k) lp[k] = acc[k];
@@ -502,9 +513,9 @@ __global__ __launch_bounds__(256) void k_final_score(const float *__restrict__ x
             int lab;
             const float cf = pixel_score<K>(acc, measure, inv_logK, lab);
             local += (double)cf;
-            if (label) label[op] = (uint8_t)lab;
-            if (mask) mask[op] = cf < threshold ? (uint8_t)0 : (uint8_t)1;
-            if (conf) conf[op] = cf;
+            if (OUT && label) label[op] = (uint8_t)lab;
+            if (OUT && mask) mask[op] = cf < threshold ? (uint8_t)0 : (uint8_t)1;
+            if (OUT && conf) conf[op] = cf;
         };
         auto tap = [&](int kh, int kw) { return wF + (kh * 3 + kw) * TS; };
         FT::load(tap(0, 0), w0);
@@ -540,10 +551,15 @@ hipError_t launch_final_score(const float *x, int N, int H, int W, const float *
     ProfScope prof("k_final_score", 2.0 * (double)N * H * W * 9 * 16 * K,
                    4.0 * ((double)N * H * W * 16 + (logits ? (double)N * 4 * H * W * K : 0.0)) +
                        (double)N * 4 * H * W * ((label ? 1 : 0) + (mask ? 1 : 0) + (conf ? 4 : 0)), s);
-#define SSAL_FS(KK)                                                                               \
-    case KK:                                                                                      \
-        hipLaunchKernelGGL(k_final_score<KK>, grid, block, 0, s, x, N, H, W, wF, logits, measure, \
-                           threshold, partial, label, mask, conf);                                \
+    const bool out = logits || label || mask || conf;
+#define SSAL_FS(KK)                                                                                        \
+    case KK:                                                                                               \
+        if (out)                                                                                           \
+            hipLaunchKernelGGL((k_final_score<KK, true>), grid, block, 0, s, x, N, H, W, wF, logits, measure, \
+                               threshold, partial, label, mask, conf);                                     \
+        else                                                                                               \
+            hipLaunchKernelGGL((k_final_score<KK, false>), grid, block, 0, s, x, N, H, W, wF, logits, measure, \
+                               threshold, partial, label, mask, conf);                                     \
         break;
     switch (K) {
         SSAL_FS(2) SSAL_FS(3) SSAL_FS(4) SSAL_FS(5) SSAL_FS(6) SSAL_FS(7) SSAL_FS(8) SSAL_FS(9)

@@ -113,11 +113,18 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # SSAL_DIST_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share
+    # the cards round-robin, collectives run on CPU tensors); the real run is one rank per GPU over RCCL
+    backend = os.environ.get("SSAL_DIST_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
 
     h, w, c, bs = args.height, args.width, args.channels, args.batch
     net = ssal.ENet(args.classes)
@@ -181,7 +188,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     log("timed region: %d steps in %.3f s on this rank" % (args.steps, elapsed))
-    t = torch.tensor([elapsed, float(frames)], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, float(frames)], dtype=torch.float64, device="cpu" if backend == "gloo" else dev)
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -105,8 +105,12 @@ def all_gather_scores(local_index, local_score, group=None):
     world = dist.get_world_size(group)
     # one collective: pack the index bits next to the score in a float64 pair -> [per, 2]
     packed = torch.stack([local_index.to(torch.float64), local_score.to(torch.float64)], dim=1).contiguous()
+    home = packed.device
+    if packed.is_cuda and dist.get_backend(group) == "gloo":
+        packed = packed.cpu()  # rehearsals of the multi-rank path on one GPU run over gloo: collectives on CPU tensors
     gathered = torch.empty((world * packed.shape[0], 2), dtype=torch.float64, device=packed.device)
     dist.all_gather_into_tensor(gathered, packed, group=group)
+    gathered = gathered.to(home)
     return gathered[:, 0].to(torch.int64), gathered[:, 1]
 
 
@@ -190,7 +194,8 @@ def _pad_to_common_length(index, score, group):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return index, score
-    n = torch.tensor([index.numel()], dtype=torch.int64, device=index.device)
+    on_cpu = index.is_cuda and dist.get_backend(group) == "gloo"
+    n = torch.tensor([index.numel()], dtype=torch.int64, device="cpu" if on_cpu else index.device)
     dist.all_reduce(n, op=dist.ReduceOp.MAX, group=group)
     pad = int(n.item()) - index.numel()
     if pad > 0:

@@ -37,6 +37,20 @@ __global__ __launch_bounds__(256) void k_probe_linear_u(const float4 *x, float4 
     }
 }
 
+// mode 14: 16 float4 per thread as in mode 10, but slab addressing: chunk k of workgroup b is float4
+// (k * gridDim + b) * 256 + t, so that at any moment all workgroups touch one compact 1/16 of the tensor
+__global__ __launch_bounds__(256) void k_probe_linear_slab(const float4 *x, float4 *y, long n4)
+{
+    constexpr int U = 16;
+    const long stride = (long)gridDim.x * 256;
+    const long base = (long)blockIdx.x * 256 + threadIdx.x;
+    float4 v[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) v[k] = base + stride * k < n4 ? x[base + stride * k] : make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < U; ++k) if (base + stride * k < n4) y[base + stride * k] = v[k];
+}
+
 // mode 9: the same 8 x 32 tile, but each wave moves its four 16-pixel groups one after the other
 // (4 loads, 4 stores, next group) instead of 16 loads followed by 16 stores
 __global__ __launch_bounds__(256) void k_probe_tile_seq(const float *x, float *y, int H, int W)
@@ -130,7 +144,7 @@ hipError_t launch_copy_probe(int mode, const float *x, float *y, int N, int H, i
     const long n = (long)N * H * W * 64;
     static const char *names[] = {"probe linear", "probe tile frag", "probe tile coalesced", "probe tile frag+halo",
                                   "probe tile coalesced+halo"};
-    if (mode < 0 || mode > 13) return hipErrorInvalidValue;
+    if (mode < 0 || mode > 14) return hipErrorInvalidValue;
     ProfScope prof(mode <= 4 ? names[mode] : "probe tile shape", 0.0, 8.0 * n, s);
     const unsigned tiles = (unsigned)((long)N * (H / 8) * (W / 32));
     switch (mode) {
@@ -151,6 +165,8 @@ hipError_t launch_copy_probe(int mode, const float *x, float *y, int N, int H, i
     case 11: hipLaunchKernelGGL((k_probe_linear_u<16, false>), dim3((unsigned)((n / 4 + 4095) / 4096)), dim3(256), 0, s,
                                 (const float4 *)x, (float4 *)y, n / 4); break;
     case 12: hipLaunchKernelGGL((k_probe_linear_u<4, true>), dim3((unsigned)((n / 4 + 1023) / 1024)), dim3(256), 0, s,
+                                (const float4 *)x, (float4 *)y, n / 4); break;
+    case 14: hipLaunchKernelGGL(k_probe_linear_slab, dim3((unsigned)((n / 4 + 4095) / 4096)), dim3(256), 0, s,
                                 (const float4 *)x, (float4 *)y, n / 4); break;
     case 13: hipLaunchKernelGGL((k_probe_linear_u<2, true>), dim3((unsigned)((n / 4 + 511) / 512)), dim3(256), 0, s,
                                 (const float4 *)x, (float4 *)y, n / 4); break;

@@ -10,7 +10,7 @@ x = torch.randn(n, h, w, 64, device="cuda"); y = torch.empty_like(x); y2 = torch
 names = ["linear", "tile 8x32 frag", "tile 8x32 coalesced", "tile 8x32 frag+halo", "tile 8x32 coalesced+halo",
          "tile 4x64 frag", "tile 2x128 frag", "tile 1x256 frag", "tile 16x16 frag", "tile 8x32 frag, group by group",
          "linear, 16 float4/thread batch", "linear, 16 float4/thread loop", "linear, 4 float4/thread batch",
-         "linear, 2 float4/thread batch"]
+         "linear, 2 float4/thread batch", "linear, 16 float4/thread batch, slab order"]
 def run(mode, spin, reps=20, out=y):
     _lib.check(L.ssal_debug_copy_probe(mode, _lib.dev_ptr(x), _lib.dev_ptr(out), n, h, w, spin, _lib.stream_ptr()))
     torch.cuda.synchronize()

@@ -64,10 +64,17 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: every rank scores --steps batches of its own shard (per-GPU work fixed); strong: the "
+                         "whole 2975-frame pool is split over the ranks (total work fixed, --steps is ignored and "
+                         "reported as the batches rank 0 ran), value = 2975 / t")
+    ap.add_argument("--allow-nondefault-knobs", action="store_true",
+                    help="measurement runs only (tools/*.sh with a -DSSAL_MEASURE library): time the library although "
+                         "ssal_debug_get_knobs() says a switch is off its default; the JSON line still reports them")
     return ap.parse_args()
 
 
-def cpu_baseline(P, h, w, c, measure, budget_s):
+def cpu_baseline(P, h, w, c, measure, budget_s, c1=None):
     """torch-CPU restatement of the reference path (oracle/torch_restatement.py) on a bounded
     sample: single 1024x2048 frames, 1 warm-up + as many repeats as fit the budget (>= 2)."""
     import torch
@@ -91,10 +98,30 @@ def cpu_baseline(P, h, w, c, measure, budget_s):
         if len(times) >= 20:
             break
     med = float(np.median(times))
-    return {"value": 1.0 / med, "unit": "images/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": "%d x 1 frame %dx%dx%d forward+%s score, torch-CPU fp32 restatement of the reference "
-                      "TF path (TensorFlow itself is not installable here), median of %d runs after 1 warm-up"
-                      % (len(times), h, w, c, measure, len(times))}
+    out = {"value": 1.0 / med, "unit": "images/s", "cores": int(torch.get_num_threads()), "kind": "port",
+           "sample": "%d x 1 frame %dx%dx%d forward+%s score, torch-CPU fp32 restatement of the reference "
+                     "TF path (TensorFlow itself is not installable here), median of %d runs after 1 warm-up"
+                     % (len(times), h, w, c, measure, len(times))}
+    if c1 is not None:
+        # BASELINE.json configs[0] / SURVEY 8(d): the reference's own CPU-runnable case, timed exactly:
+        # 4 x 256x512x3 frames -> forward + entropy score + top-1 select
+        P1, k1 = c1
+        x1 = syn.synth_frames_f32([0, 1, 2, 3], 256, 512, 3)
+        tr.score_images(P1, x1, "entropy")
+        t1 = []
+        while len(t1) < 3 or sum(t1) < 3.0:
+            t0 = time.perf_counter()
+            mean = tr.score_images(P1, x1, "entropy")[0]
+            np.argpartition(np.asarray(mean, dtype=np.float32), 1)[:1]
+            t1.append(time.perf_counter() - t0)
+            if len(t1) >= 30:
+                break
+        m1 = float(np.median(t1))
+        log("cpu baseline C1 (4 x 256x512): %.3f s" % m1)
+        out["c1"] = {"value": 4.0 / m1, "unit": "images/s", "cores": int(torch.get_num_threads()), "kind": "port",
+                     "sample": "configs[0]: %d x (4 frames 256x512x3, K=%d: forward + entropy + top-1), median"
+                               % (len(t1), k1)}
+    return out
 
 
 def main():
@@ -126,6 +153,10 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
 
+    knobs = _lib.get_knobs()
+    if not knobs["defaults"] and not args.allow_nondefault_knobs:
+        raise SystemExit("refusing to time a library whose switches are not at their shipping values: %s" % knobs)
+
     h, w, c, bs = args.height, args.width, args.channels, args.batch
     net = ssal.ENet(args.classes)
     net.build((None, None, None, c))
@@ -138,6 +169,10 @@ def main():
     in_dtype = torch.uint8 if args.input_dtype == "u8" else torch.float32
     bytes_per_batch = bs * h * w * c * (1 if args.input_dtype == "u8" else 4)
     max_resident = max(1, int(args.resident_gib * 2 ** 30 // bytes_per_batch))
+    if args.scaling == "strong":
+        # total work fixed: this rank scores its whole shard of the 2975-frame pool, once
+        args.steps = n_batches_shard
+        args.warmup = min(args.warmup, 2)
     need = min(args.steps + args.warmup, n_batches_shard)
     n_resident = min(need, max_resident)
     batches = []
@@ -165,7 +200,10 @@ def main():
         return torch.cat(idx_chunks), torch.cat(score_chunks), frames
 
     def merge_and_select(index, score):
-        index, score = al._pad_to_common_length(index, score, None)
+        # ONE collective: every rank ran the same number of steps, so each pads its (index, score) shard locally
+        # to steps * batch entries (a shard's last batch may be short) and all-gathers it
+        if world > 1:
+            index, score = al.pad_to_length(index, score, max(args.steps, args.warmup, 1) * bs)
         all_index, all_score = al.all_gather_scores(index, score)
         return al.finish_ranking(all_index.cpu().numpy(), all_score.cpu().numpy(), POOL,
                                  np.arange(POOL), TOP_K)
@@ -181,7 +219,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    index, score, frames = run_steps(args.steps, args.warmup)
+    index, score, frames = run_steps(args.steps, 0 if args.scaling == "strong" else args.warmup)
     low, _ = merge_and_select(index, score)
     torch.cuda.synchronize()
     if world > 1:
@@ -205,13 +243,14 @@ def main():
             "metric": "unlabelled-pool images/sec scored (ENet, 1024x2048)",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: ENet pool of %d synthetic %dx%dx%d frames, %s acquisition, "
                                    "batch %d, K=%d, top-%d select%s" % (POOL, h, w, c, args.measure, bs, args.classes, TOP_K,
                                                                         ", uint8 resident frames" if args.input_dtype == "u8" else ""),
                        "frames_scored": int(total_frames), "resident_batches_per_rank": n_resident,
                        "sharding": "strided pool shard per rank, one all-gather of (index, score)"},
+            "knobs": knobs,
         }
 
     # ---- roofline leg: per-kernel HIP-event timing of one extra batch (rank 0, outside the clock) --
@@ -258,11 +297,16 @@ def main():
     # ---- CPU baseline leg (rank 0, N=1 only) ------------------------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         P = syn.enet_params_dict(net)
-        result["cpu_baseline"] = cpu_baseline(P, h, w, c, args.measure, args.cpu_seconds)
+        net1 = ssal.ENet(19)
+        net1.build((None, None, None, 3))
+        syn.randomize_enet(net1, seed=0)
+        result["cpu_baseline"] = cpu_baseline(P, h, w, c, args.measure, args.cpu_seconds,
+                                              c1=(syn.enet_params_dict(net1), 19))
         result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
 
     if rank == 0:
-        result["top_k_checksum"] = int(np.sort(low).astype(np.int64).sum())
+        # only meaningful when the whole pool was scored (default --steps 372 at N=1, or --scaling strong)
+        result["top_k_checksum"] = int(np.sort(low).astype(np.int64).sum()) if int(total_frames) >= POOL else None
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -91,6 +91,13 @@ int ssal_enet_score_nhwc_u8(ssal_enet *net, const uint8_t *x_dev, int n, int h, 
  * offs[1] bottleneck4_2 [n,h/4,w/4,64], offs[2] bottleneck3_8 [n,h/8,w/8,128]. */
 int ssal_enet_endpoint_offsets(const ssal_enet *net, int n, int h, int w, int64_t offs[3]);
 
+/* The max-pooling indices ENet.call hands from Bottleneck1_0 / Bottleneck2_0 to Bottleneck5_0 / Bottleneck4_0
+ * (models/enet/enet.py:331,338,359,364), of the LAST forward/score call that ran on this workspace, converted from
+ * the internal 1-byte window codes to the reference's int64 per-image index (y*W + x)*C + c:
+ * which = 1 -> argmax1 [n,h/4,w/4,16], which = 2 -> argmax2 [n,h/8,w/8,64]. */
+int ssal_enet_export_argmax(const ssal_enet *net, const void *ws_dev, int64_t ws_bytes, int n, int h, int w,
+                            int which, int64_t *argmax_out_dev, void *stream);
+
 /* Run ONE layer of the handle (Layer.__call__ of enet_modules.py: Initial :190-224, Bottleneck
  * :526-599, BottleneckDownsample :868-938, BottleneckUpsample :1217-1292, Final :1359-1381).
  * x_dev [n,h,w,cin] -> y_dev (shape by layer kind).  argmax tensors use the reference's int64
@@ -126,12 +133,20 @@ int ssal_masked_softmax_cross_entropy(const float *logits_dev, const uint8_t *la
  * include_batch selects the TF<=1.13 CPU index convention (extra_ops.py:63-81). */
 int ssal_max_pool_with_argmax_2x2(const float *x_dev, int n, int h, int w, int c, float *y_dev,
                                   int64_t *argmax_dev, int include_batch, void *stream);
-/* xops.unpool_2d(inputs, idx, strides=[1,2,2,1])  (models/util/extra_ops.py:28-86) */
+/* xops.unpool_2d(inputs, idx, strides=[1,2,2,1])  (models/util/extra_ops.py:28-86).  Indices must be unique per
+ * output element (true of pooling-derived indices, the reference's only use): tf.scatter_nd sums duplicates, this
+ * scatter assigns. */
 int ssal_unpool_2d(const float *x_dev, const int64_t *idx_dev, int n, int h, int w, int c,
                    int idx_has_batch, float *y_dev, void *stream);
 /* xops.prelu(x, alpha)  (models/util/extra_ops.py:9-26) */
 int ssal_prelu(const float *x_dev, int64_t pixels, int c, const float *alpha_dev, float *y_dev,
                void *stream);
+/* xops.spatial_dropout(inputs, drop_rate)  (models/util/extra_ops.py:137-151; called, training only, at
+ * enet_modules.py:591-594): tf.nn.dropout with noise_shape [N,1,1,C]: y = (x / (1-rate)) * floor((1-rate) + u[n,c]),
+ * one uniform draw per (image, channel) plane.  u is a counter-based hash of (seed, n*C + c) -- TensorFlow's random
+ * stream is not reproducible, the distribution and the arithmetic are.  x_dev/y_dev [n, pixels_per_image, c]. */
+int ssal_spatial_dropout(const float *x_dev, int n, int64_t pixels_per_image, int c, float rate, uint64_t seed,
+                         float *y_dev, void *stream);
 /* xops.batch_norm(..., training=False)  (models/util/extra_ops.py:154-185) */
 int ssal_batch_norm_inference(const float *x_dev, int64_t pixels, int c, const float *mean_dev,
                               const float *var_dev, const float *gamma_dev, const float *beta_dev,
@@ -170,10 +185,16 @@ int ssal_debug_probe(float *out_dev_256, void *stream);
  * independent accumulators per wave; out_dev needs blocks*256 floats.  Time it with ssal_profile_*. */
 int ssal_debug_mfma_peak(int shape, int blocks, int iters, float *out_dev, void *stream);
 
-/* tuning / A-B knob of the fused bottleneck launchers ("bnk_tw": 16 forces 8x16 tiles, "bnk_xcd": 0 switches
- * the XCD-aware tile order off, "ablate": phase ablation for timing; defaults come from the SSAL_BNK_TW /
- * SSAL_BNK_XCD / SSAL_ABLATE environment).  Every "bnk_tw" / "bnk_xcd" setting produces bit-identical results (tests/test_gpu_parity.py); SSAL_EINVAL for an unknown name. */
+/* tuning / A-B knob of the fused bottleneck launchers ("bnk_tw": 16 forces 8x16 tiles, "bnk_xcd": 0 switches the
+ * XCD-aware tile order off).  Every setting produces bit-identical results (tests/test_gpu_parity.py); SSAL_EINVAL for
+ * an unknown name.  The product build reads no environment variable and contains no work-skipping switch: phase
+ * ablation ("ablate") and the SSAL_* environment defaults exist only in -DSSAL_MEASURE builds (tools/phase_trace.py),
+ * whose ssal_version() says so. */
 int ssal_debug_set_knob(const char *name, int value);
+/* JSON object with the state of every switch that can change what a launch does or costs: kernel_family, bnk_tw,
+ * bnk_xcd, ablate, measure_build, profiling, defaults (1 iff all are at their shipping values).  bench.py prints it
+ * in its result line and refuses to time anything else. */
+int ssal_debug_get_knobs(char *json_out, int64_t cap);
 
 /* measurement aid (tools/mem_probe.py): y = x for an [n,h,w,64] tensor with the access shape `mode`
  * (0 linear, 1 MFMA-fragment tile, 2 coalesced tile, 3/4 = 1/2 + halo-ring reads, 5-8 other tile shapes, 9 group by group, 10-13 linear with 16 / 16 / 4 / 2 float4 per thread, 14 = 10 in slab order); h % 8 == 0, w % 32 == 0;

@@ -35,6 +35,7 @@ PROTOTYPES = {
     "ssal_enet_forward_nhwc_u8": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i64, _vp]),
     "ssal_enet_score_nhwc_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "ssal_enet_endpoint_offsets": (_i, [_vp, _i, _i, _i, _c.POINTER(_i64)]),
+    "ssal_enet_export_argmax": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp]),
     "ssal_enet_run_layer": (_i, [_vp, _c.c_char_p, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
     "ssal_enet_layer_workspace_bytes": (_i64, [_vp, _c.c_char_p, _i, _i, _i]),
     "ssal_score_workspace_bytes": (_i64, [_i, _i, _i]),
@@ -44,6 +45,7 @@ PROTOTYPES = {
     "ssal_max_pool_with_argmax_2x2": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "ssal_unpool_2d": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ssal_prelu": (_i, [_vp, _i64, _i, _vp, _vp, _vp]),
+    "ssal_spatial_dropout": (_i, [_vp, _i, _i64, _i, _f, _c.c_uint64, _vp, _vp]),
     "ssal_batch_norm_inference": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ssal_conv2d_same": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ssal_conv2d_transpose_3x3_s2": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
@@ -55,6 +57,7 @@ PROTOTYPES = {
     "ssal_debug_mfma_peak": (_i, [_i, _i, _i, _vp, _vp]),
     "ssal_debug_set_trace": (_i, [_vp, _i64]),
     "ssal_debug_set_knob": (_i, [ctypes.c_char_p, _i]),
+    "ssal_debug_get_knobs": (_i, [_c.c_char_p, _i64]),
     "ssal_debug_copy_probe": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ssal_profile_enable": (_i, [_i]),
     "ssal_profile_collect": (_i, [_c.c_char_p, _i64]),
@@ -203,6 +206,16 @@ def profile_collect():
 def set_kernel_family(use_mfma=True):
     """A/B switch: MFMA-fused bottleneck kernels (default) vs the generic kernels; bit-identical."""
     check(lib().ssal_set_kernel_family(1 if use_mfma else 0))
+
+
+def get_knobs():
+    """state of every switch that can change what a launch does (include/ssal_enet.h: ssal_debug_get_knobs)"""
+    import json
+    buf = ctypes.create_string_buffer(512)
+    check(lib().ssal_debug_get_knobs(buf, len(buf)))
+    out = json.loads(buf.value.decode())
+    out["version"] = lib().ssal_version().decode()
+    return out
 
 
 def set_knob(name, value):

@@ -139,6 +139,9 @@ def prefetch_to_device(batches, depth=2):
             dev = host.cuda(non_blocking=True)
             done = torch.cuda.Event()
             done.record(copy_stream)
+        issued = getattr(images, "_ssal_copy_issued", None)
+        if issued is not None:
+            issued(done)  # page-locked ring slot of tensortools.input.InputStage: not rewritten before `done`
         return dev, indices, done, host  # the host buffer must outlive the copy
 
     def release(entry):
@@ -157,16 +160,35 @@ def prefetch_to_device(batches, depth=2):
         yield release(queue.popleft())
 
 
+def pad_to_length(index, score, length):
+    """Local (collective-free) padding of one rank's ``(index, score)`` shard to ``length`` entries with the
+    ``(-1, +inf)`` sentinel.  ``shard_positions`` gives every rank ``ceil(num_examples / world)`` positions, so
+    a rank that scored its whole shard pads to exactly that length without asking the others."""
+    import torch
+    pad = int(length) - index.numel()
+    if pad < 0:
+        raise ValueError("shard has %d entries, more than the per-rank length %d" % (index.numel(), length))
+    if pad > 0:
+        index = torch.cat([index, torch.full((pad,), -1, dtype=torch.int64, device=index.device)])
+        score = torch.cat([score, torch.full((pad,), float("inf"), dtype=torch.float64, device=score.device)])
+    return index, score
+
+
 def rank_confidence(net, batches, num_examples, unlabelled, selection_size, measure="entropy",
-                    group=None, prefetch=0):
+                    group=None, prefetch=0, ragged=False):
     """Mirror of ``rank_confidence()`` (reference :682-715).
 
     ``batches`` yields ``(images NHWC float32 or uint8, example_indices)``; on a multi-GPU job each rank
-    passes only its own shard.  ``prefetch`` > 0 copies host batches that many batches ahead on a side
-    stream (``prefetch_to_device``).  Returns ``(low_conf_examples, unlabelled_confidence)``: the ids (into
-    the full example list) of the ``selection_size`` least confident unlabelled examples and the
-    float32 confidence of every unlabelled example (the reference feeds it to a histogram summary,
-    :781-784)."""
+    passes only its own shard (``shard_positions``).  ``prefetch`` > 0 copies host batches that many batches
+    ahead on a side stream (``prefetch_to_device``).  Returns ``(low_conf_examples, unlabelled_confidence)``:
+    the ids (into the full example list) of the ``selection_size`` least confident unlabelled examples and
+    the float32 confidence of every unlabelled example (the reference feeds it to a histogram summary,
+    :781-784).
+
+    Collectives per ranking pass: exactly ONE all-gather of ``(index, score)`` pairs.  Shards handed out by
+    ``shard_positions`` hold at most ``ceil(num_examples / world)`` examples, so each rank pads locally to that
+    length.  ``ragged=True`` is for callers that split the pool some other way (shard lengths unknown to the
+    other ranks): it costs one extra all-reduce(MAX) to agree on the length."""
     torch = _lib.require_gpu()
     idx_chunks, score_chunks = [], []
     if prefetch > 0:
@@ -182,14 +204,26 @@ def rank_confidence(net, batches, num_examples, unlabelled, selection_size, meas
         dev = torch.device("cuda", torch.cuda.current_device())
         local_score = torch.zeros((0,), dtype=torch.float64, device=dev)
         local_index = torch.zeros((0,), dtype=torch.int64, device=dev)
-    local_index, local_score = _pad_to_common_length(local_index, local_score, group)
+    return merge_and_rank(local_index, local_score, num_examples, unlabelled, selection_size, group, ragged)
+
+
+def merge_and_rank(local_index, local_score, num_examples, unlabelled, selection_size, group=None, ragged=False):
+    """the collective + host tail of a ranking pass (shared by ``rank_confidence`` and ``bench.py``)"""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    if world > 1:
+        if ragged:
+            local_index, local_score = _pad_to_common_length(local_index, local_score, group)
+        else:
+            local_index, local_score = pad_to_length(local_index, local_score, (num_examples + world - 1) // world)
     all_index, all_score = all_gather_scores(local_index, local_score, group)
     return finish_ranking(all_index.cpu().numpy(), all_score.cpu().numpy(), num_examples,
                           unlabelled, selection_size)
 
 
 def _pad_to_common_length(index, score, group):
-    """all_gather_into_tensor needs equal shard lengths: pad with the (-1, +inf) sentinel."""
+    """Ragged callers only: all_gather_into_tensor needs equal shard lengths, and nobody knows the longest
+    one, so agree on it with one all-reduce(MAX), then pad with the (-1, +inf) sentinel."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
@@ -197,11 +231,7 @@ def _pad_to_common_length(index, score, group):
     on_cpu = index.is_cuda and dist.get_backend(group) == "gloo"
     n = torch.tensor([index.numel()], dtype=torch.int64, device="cpu" if on_cpu else index.device)
     dist.all_reduce(n, op=dist.ReduceOp.MAX, group=group)
-    pad = int(n.item()) - index.numel()
-    if pad > 0:
-        index = torch.cat([index, torch.full((pad,), -1, dtype=torch.int64, device=index.device)])
-        score = torch.cat([score, torch.full((pad,), float("inf"), dtype=torch.float64, device=score.device)])
-    return index, score
+    return pad_to_length(index, score, int(n.item()))
 
 
 def finish_ranking(all_index, all_score, num_examples, unlabelled, selection_size):

@@ -1,35 +1,60 @@
 """Build recipe of libssal_hip.so: hipcc, gfx950 only, in-tree (the .so travels with the repo
-snapshot to the GPU box)."""
+snapshot to the GPU box).  Every csrc/*.hip is compiled to its own object (in parallel, cached by a
+content hash of the source, the headers and the flags) and the objects are linked into one shared
+library."""
+import concurrent.futures
+import hashlib
 import os
 import shutil
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, ".obj")
 OUT = os.path.join(HERE, "libssal_hip.so")
 
 # -ffp-contract=off: every fused multiply-add in the kernels is an explicit fmaf(), so results are
 # bit-comparable with the parity oracle (which is built the same way).
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-fvisibility=hidden", "-Wall"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+          "-fvisibility=hidden", "-Wall"]
+FLAGS = CFLAGS + ["-shared"]  # one-shot form (tools/phase_trace.py builds its measurement variant with it)
 
 
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def _headers():
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    inc = os.path.join(HERE, "..", "include")
+    deps += sorted(os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h"))
+    return deps
+
+
 STAMP = OUT + ".stamp"
+
+
+def _header_hash():
+    h = hashlib.sha256(" ".join(CFLAGS).encode())
+    for d in _headers():
+        h.update(os.path.basename(d).encode())
+        h.update(open(d, "rb").read())
+    return h
+
+
+def _source_digest(src, hh):
+    h = hh.copy()
+    h.update(os.path.basename(src).encode())
+    h.update(open(src, "rb").read())
+    return h.hexdigest()
 
 
 def _digest():
     """content hash of every input of the build (mtimes do not survive a repo snapshot copy)"""
-    import hashlib
-    h = hashlib.sha256(" ".join(FLAGS).encode())
-    deps = sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
-    deps.append(os.path.join(HERE, "..", "include", "ssal_enet.h"))
-    for d in deps:
-        h.update(os.path.basename(d).encode())
-        h.update(open(d, "rb").read())
+    hh = _header_hash()
+    h = hashlib.sha256()
+    for s in sources():
+        h.update(_source_digest(s, hh).encode())
     return h.hexdigest()
 
 
@@ -39,11 +64,35 @@ def needs_build():
     return open(STAMP).read().strip() != _digest()
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, jobs=None):
     if not force and not needs_build():
         return OUT
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + FLAGS + ["-o", OUT + ".tmp"] + sources()
+    os.makedirs(OBJ, exist_ok=True)
+    hh = _header_hash()
+    objs, todo = [], []
+    for src in sources():
+        base = os.path.basename(src)[:-4]
+        obj = os.path.join(OBJ, "%s.%s.o" % (base, _source_digest(src, hh)[:16]))
+        objs.append(obj)
+        if force or not os.path.exists(obj):
+            todo.append((src, obj, base))
+
+    def compile_one(item):
+        src, obj, base = item
+        for old in os.listdir(OBJ):  # drop stale objects of this source
+            if old.startswith(base + ".") and os.path.join(OBJ, old) != obj:
+                os.remove(os.path.join(OBJ, old))
+        cmd = [hipcc] + CFLAGS + ["-c", src, "-o", obj + ".tmp"]
+        if verbose:
+            print("[ssal build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        os.replace(obj + ".tmp", obj)
+
+    if todo:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=jobs or min(len(todo), 6)) as ex:
+            list(ex.map(compile_one, todo))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT + ".tmp"] + objs
     if verbose:
         print("[ssal build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
@@ -54,4 +103,5 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force=True)
+    import sys
+    build(force="--force" in sys.argv)

@@ -38,7 +38,13 @@ static int fail(int code, const char *fmt, ...)
             return fail(SSAL_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_));      \
     } while (0)
 
-SSAL_API const char *ssal_version(void) { return "ssal-hip 0.1 (gfx950)"; }
+SSAL_API const char *ssal_version(void) { 
+#ifdef SSAL_MEASURE
+    return "ssal-hip 0.2 (gfx950, MEASUREMENT build: not for results)";
+#else
+    return "ssal-hip 0.2 (gfx950)";
+#endif
+ }
 SSAL_API const char *ssal_last_error(void) { return g_err; }
 
 // ------------------------------------------------------------------------------------------------
@@ -802,6 +808,25 @@ SSAL_API int ssal_enet_endpoint_offsets(const ssal_enet *net, int n, int h, int 
     return SSAL_OK;
 }
 
+// The pooling indices of the last forward/score call that used this workspace, in the reference's int64 form
+// (argmax1 of Bottleneck1_0: [n,h/4,w/4,16]; argmax2 of Bottleneck2_0: [n,h/8,w/8,64]; enet.py:331,338).
+SSAL_API int ssal_enet_export_argmax(const ssal_enet *net, const void *ws_dev, int64_t ws_bytes, int n, int h, int w,
+                                     int which, int64_t *argmax_out_dev, void *stream)
+{
+    int rc = check_dims(net, n, h, w);
+    if (rc) return rc;
+    if (!ws_dev || !argmax_out_dev) return fail(SSAL_EINVAL, "NULL device pointer");
+    if (which != 1 && which != 2) return fail(SSAL_EINVAL, "which must be 1 (argmax1) or 2 (argmax2), got %d", which);
+    NetWorkspace W = carve(net, const_cast<void *>(ws_dev), ws_bytes, n, h, w);
+    if (!W.ok) return fail(SSAL_ENOMEM, "workspace too small: need %lld bytes, got %lld", (long long)W.bytes,
+                           (long long)ws_bytes);
+    if (which == 1)
+        HIP_TRY(launch_codes_to_argmax(W.code1, n, h / 4, w / 4, 16, argmax_out_dev, (hipStream_t)stream));
+    else
+        HIP_TRY(launch_codes_to_argmax(W.code2, n, h / 8, w / 8, 64, argmax_out_dev, (hipStream_t)stream));
+    return SSAL_OK;
+}
+
 // ---- single layer -------------------------------------------------------------------------------
 static int find_layer(const ssal_enet *net, const char *layer)
 {
@@ -979,6 +1004,16 @@ SSAL_API int ssal_prelu(const float *x_dev, int64_t pixels, int c, const float *
     return SSAL_OK;
 }
 
+SSAL_API int ssal_spatial_dropout(const float *x_dev, int n, int64_t pixels_per_image, int c, float rate,
+                                  uint64_t seed, float *y_dev, void *stream)
+{
+    if (!x_dev || !y_dev) return fail(SSAL_EINVAL, "NULL device pointer");
+    if (n <= 0 || pixels_per_image <= 0 || c <= 0) return fail(SSAL_EINVAL, "bad dims");
+    if (!(rate >= 0.0f && rate < 1.0f)) return fail(SSAL_EINVAL, "rate must be in [0, 1) (got %g)", (double)rate);
+    HIP_TRY(launch_spatial_dropout(x_dev, n, pixels_per_image, c, rate, seed, y_dev, (hipStream_t)stream));
+    return SSAL_OK;
+}
+
 SSAL_API int ssal_batch_norm_inference(const float *x_dev, int64_t pixels, int c,
                                        const float *mean_dev, const float *var_dev,
                                        const float *gamma_dev, const float *beta_dev, float *y_dev,
@@ -1136,8 +1171,29 @@ SSAL_API int ssal_debug_set_knob(const char *name, int value)
     const std::string n(name);
     if (n == "bnk_tw") k.bnk_tw = value;
     else if (n == "bnk_xcd") k.bnk_xcd = value;
+#ifdef SSAL_MEASURE
     else if (n == "ablate") k.ablate = value;
-    else return fail(SSAL_EINVAL, "unknown knob");
+#endif
+    else return fail(SSAL_EINVAL, "unknown knob '%s'", name);
+    return SSAL_OK;
+}
+
+// {"kernel_family": 1, "bnk_tw": 0, "bnk_xcd": 1, "measure_build": 0, "defaults": 1}; bench.py prints it and
+// refuses to time a library whose knobs are not at their defaults
+SSAL_API int ssal_debug_get_knobs(char *json_out, int64_t cap)
+{
+    if (!json_out || cap < 160) return fail(SSAL_EINVAL, "json_out too small");
+    const ssal::Knobs &k = ssal::knobs();
+    int measure = 0, ablate = 0;
+#ifdef SSAL_MEASURE
+    measure = 1;
+    ablate = k.ablate;
+#endif
+    const int dflt = g_use_mfma && k.bnk_tw == 0 && k.bnk_xcd == 1 && ablate == 0 && !ssal::prof_enabled()
+                     && ssal::g_trace_buf == nullptr;
+    snprintf(json_out, (size_t)cap, "{\"kernel_family\": %d, \"bnk_tw\": %d, \"bnk_xcd\": %d, \"ablate\": %d, "
+             "\"measure_build\": %d, \"profiling\": %d, \"defaults\": %d}", g_use_mfma ? 1 : 0, k.bnk_tw, k.bnk_xcd,
+             ablate, measure, ssal::prof_enabled() ? 1 : 0, dflt);
     return SSAL_OK;
 }
 

@@ -5,6 +5,17 @@
 #pragma once
 #include <stdint.h>
 
+// SSAL_MEASURE: measurement-only code (phase ablation, environment-driven launcher knobs).  Never defined in the
+// product build of libssal_hip.so (build.py); tools/phase_trace.py builds its private variant with it.
+#if defined(SSAL_PHASE_TRACE) && !defined(SSAL_MEASURE)
+#define SSAL_MEASURE 1
+#endif
+#ifdef SSAL_MEASURE
+#define SSAL_ABLATE_IS(args, v) ((args).ablate == (v))
+#else
+#define SSAL_ABLATE_IS(args, v) false
+#endif
+
 namespace ssal {
 
 // regular / dilated / asymmetric bottleneck (enet_modules.py:526-599)
@@ -20,8 +31,10 @@ struct BnkArgs {
     int tiles_y, tiles_x;  // tiles per phase sub-image (sized for the largest phase)
     unsigned long long *trace;  // phase-trace buffer (NULL unless a -DSSAL_PHASE_TRACE build is being traced)
     int ntiles, xcd_chunk;  // XCD-aware tile order: tile = (b % 8) * xcd_chunk + b / 8 (xcd_chunk = 0: tile = b)
-    int ablate;            // measurement aid (SSAL_ABLATE env): 1 = stop after the projection phase,
+#ifdef SSAL_MEASURE
+    int ablate;            // measurement builds only (tools/phase_trace.py): 1 = stop after the projection phase,
                            // 2 = skip the projection phase (results invalid; timing only)
+#endif
 };
 
 // downsample bottleneck (enet_modules.py:868-938)

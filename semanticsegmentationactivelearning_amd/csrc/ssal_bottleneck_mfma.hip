@@ -384,12 +384,12 @@ __global__ __launch_bounds__(256, 3) void k_bottleneck_mfma(BnkArgs a)
     tr.mark(0);
     const float *ximg = a.x + (long)t.n * a.H * a.W * C;
     float *yimg = a.y + (long)t.n * a.H * a.W * C;
-    if (a.ablate != 2)
+    if (!SSAL_ABLATE_IS(a, 2))
         proj_to_lds<TW, 1>(a, ximg, P, t.TH, t.ty0, t.tx0, t.py, t.px, t.Hp, t.Wp, wave, j, h);
     tr.mark(1);
     __syncthreads();
     tr.mark(2);
-    if (a.ablate == 1) return;
+    if (SSAL_ABLATE_IS(a, 1)) return;
     conv_exp_store<TW, 3, 3, TW + 2>(a, ximg, yimg, P, a.wc, t.TH, t.ty0, t.tx0, t.py, t.px, t.Hp,
                                      t.Wp, wave, j, h, tr);
 #ifdef SSAL_PHASE_TRACE
@@ -1049,11 +1049,15 @@ hipError_t launch_mfma_peak(int shape, int blocks, int iters, float *out, hipStr
 Knobs &knobs()
 {
     static Knobs k = [] {
-        auto env = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
         Knobs q;
+        q.bnk_tw = 0;
+        q.bnk_xcd = 1;
+#ifdef SSAL_MEASURE  // measurement builds only: the product library reads no environment
+        auto env = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
         q.bnk_tw = env("SSAL_BNK_TW", 0);
         q.bnk_xcd = env("SSAL_BNK_XCD", 1);
         q.ablate = env("SSAL_ABLATE", 0);
+#endif
         return q;
     }();
     return k;
@@ -1174,7 +1178,9 @@ hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W,
     a.we = we; a.es = es; a.et = et; a.ra = ra;
     a.N = N; a.H = H; a.W = W; a.dil = dil;
     const Knobs &kn = knobs();
+#ifdef SSAL_MEASURE
     a.ablate = kn.ablate;
+#endif
     a.trace = nullptr;
     if (Cin != C) return launch_bottleneck_mfma16(a, Cin, s);
     a.TH = 8;

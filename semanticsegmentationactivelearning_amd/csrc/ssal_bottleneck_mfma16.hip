@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256, 3) void k_bottleneck16(BnkArgs a)
         int qrow[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) qrow[r] = q_center(mt * 16 + 4 * g + r);
-        if (a.ablate != 2) project(xk[k], vmask, qrow);
+        if (!SSAL_ABLATE_IS(a, 2)) project(xk[k], vmask, qrow);
     }
     tr.mark(1);  // centre projected (activation loads have arrived)
 #pragma unroll
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256, 3) void k_bottleneck16(BnkArgs a)
                 const int ur = mtr * 16 + 4 * g + r;
                 qrow[r] = ur < RING ? q_ring(ur) : -1;
             }
-            if (a.ablate != 2) project(xr[k], vmask, qrow);
+            if (!SSAL_ABLATE_IS(a, 2)) project(xr[k], vmask, qrow);
         }
     }
 
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256, 3) void k_bottleneck16(BnkArgs a)
     tr.mark(2);  // ring projected, phase-B operands requested
     __syncthreads();
     tr.mark(3);
-    if (a.ablate == 1) return;
+    if (SSAL_ABLATE_IS(a, 1)) return;
 
     // ---- phase B: conv, expansion, residual (from registers), store -------------------------------
 #pragma unroll

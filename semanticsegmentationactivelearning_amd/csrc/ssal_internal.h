@@ -97,13 +97,16 @@ hipError_t launch_upsample_mfma(const float *x, float *y, const uint8_t *code, i
                                 const float *ws, const float *cs, const float *ct, const float *ca,
                                 const float *we, const float *es, const float *et, const float *wr,
                                 const float *ra, hipStream_t s);
-// Tuning / measurement knobs of the fused bottleneck launchers (defaults = the shipping configuration;
-// initialised from the SSAL_* environment once, changed at run time with ssal_debug_set_knob for A/B runs
-// and for the tests that compare the variants bit for bit).
+// Tuning knobs of the fused bottleneck launchers (defaults = the shipping configuration; changed at run time with
+// ssal_debug_set_knob for A/B runs and for the tests that compare the variants bit for bit: every setting of the
+// product build produces identical results.  Work-skipping "ablate" and the SSAL_* environment reads exist only in
+// -DSSAL_MEASURE builds).
 struct Knobs {
     int bnk_tw;      // 16 = force 8x16 tiles in the 128-channel bottleneck kernels
     int bnk_xcd;     // 1 = XCD-aware tile order in the 128-channel bottleneck kernels
-    int ablate;      // 1 = stop after the projection phase, 2 = skip it (timing only, results invalid)
+#ifdef SSAL_MEASURE
+    int ablate;      // measurement builds only: 1 = stop after the projection phase, 2 = skip it (results invalid)
+#endif
 };
 Knobs &knobs();
 
@@ -120,6 +123,9 @@ hipError_t launch_affine(const float *x, int64_t pixels, int C, const float *sca
                          const float *shift, float *y, hipStream_t s);
 hipError_t launch_bn_fold(const float *mean, const float *var, const float *gamma,
                           const float *beta, int C, float *scale, float *shift, hipStream_t s);
+// xops.spatial_dropout (extra_ops.py:137-151): y = (x / (1-rate)) * floor(1-rate + u(n,c)), u = hash(seed, n*C + c)
+hipError_t launch_spatial_dropout(const float *x, int N, int64_t pixels_per_image, int C, float rate, uint64_t seed,
+                                  float *y, hipStream_t s);
 hipError_t launch_resize_bilinear(const float *x, int N, int H, int W, int C, int OH, int OW,
                                   float *y, hipStream_t s);
 hipError_t launch_synth_frames(uint64_t seed, int64_t first, int count, int H, int W, int C,

@@ -330,6 +330,11 @@ hipError_t launch_convT(const float *x, int N, int H, int W, int Cin, const floa
 //   margin    : conf = p_(1) - p_(2) = (1 - e_(2)) / S
 //   confidence: conf = p_(1) = 1 / S
 // label = first maximum of the logits (tf.math.argmax, :234-236).
+// Non-finite logits (policy, tests/test_gpu_parity.py::test_score_nonfinite_policy):
+//   * exp underflow (x_k - m < -104) and x_k = -inf give p_k = 0 exactly and contribute 0 to H -- the value the
+//     reference's  -p * log(p + FLT_MIN)  takes at p = 0;
+//   * a NaN logit, or a +inf maximum (inf - inf in the softmax), makes the pixel's confidence NaN, as the
+//     reference's tf.nn.softmax does; the per-image mean is then NaN and np.argpartition ranks it last.
 // ------------------------------------------------------------------------------------------------
 template <int K>
 __device__ __forceinline__ float pixel_score(const float (&l)[K], int measure, float inv_logK,
@@ -344,7 +349,8 @@ __device__ __forceinline__ float pixel_score(const float (&l)[K], int measure, f
     float S = 0.0f, T = 0.0f, e2 = 0.0f;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const float d = l[k] - m;
+        // -inf logits (p = 0 exactly, like the reference's softmax): keep 0 * d finite so T stays a number
+        const float d = fmaxf(l[k] - m, -3.0e38f);
         const float e = __expf(d);
         S += e;
         T = fmaf(e, d, T);

@@ -74,6 +74,7 @@ class ENet:
         self._pushed_versions = None
         self._ws = None
         self._endpoints = []
+        self._last_dims = None
         self.outputs = []
 
     # ---- keras-like surface ----------------------------------------------------------------
@@ -86,6 +87,25 @@ class ENet:
         return [v for l in self.layers for v in l.variables]
 
     weights = variables
+
+    def assign_named(self, named, strict=False):
+        """Name-keyed weight copy: ``named`` maps variable names to arrays.  Names are matched on
+        ``<Layer>/<weight path>`` -- a leading model scope (``ENet/``) and a trailing ``:0`` as in
+        ``{v.name: sess.run(v) for v in tf_net.variables}`` are ignored.  Unknown names raise KeyError;
+        with ``strict`` every variable of the model must be present.  Returns the number assigned."""
+        mine = {v.name: v for v in self.variables}
+        seen = set()
+        for name, value in named.items():
+            key = name[:-2] if name.endswith(":0") else name
+            while key not in mine and "/" in key:
+                key = key.split("/", 1)[1]
+            if key not in mine:
+                raise KeyError("no variable of %s matches '%s'" % (self.name, name))
+            mine[key].assign(value)
+            seen.add(key)
+        if strict and len(seen) != len(mine):
+            raise KeyError("missing variables: %s" % sorted(set(mine) - seen)[:5])
+        return len(seen)
 
     def build(self, input_shape):
         """Create all weights for an NHWC input shape (reference build :249-309 + lazy layer builds)."""
@@ -101,9 +121,9 @@ class ENet:
 
     @property
     def endpoint_outputs(self):
-        """[[final, bottleneck5_1, bottleneck4_2, bottleneck3_8], ...] one entry per call
-        (reference :311-318).  The three intermediate tensors are views into the device workspace
-        of the most recent call and are overwritten by the next one."""
+        """[[final, bottleneck5_1, bottleneck4_2, bottleneck3_8]] of the most recent call (the reference
+        keeps one entry per graph build, :311-318; eager calls would pile up device memory).  The three
+        intermediate tensors are views into the device workspace and are overwritten by the next call."""
         return list(self._endpoints)
 
     # ---- device handle ---------------------------------------------------------------------
@@ -177,7 +197,11 @@ class ENet:
             _lib.check(fwd(handle, _lib.dev_ptr(x), n, h, w, _lib.dev_ptr(logits),
                            _lib.dev_ptr(ws), ws.numel(), _lib.stream_ptr()))
             self._record_endpoints(logits, ws, n, h, w)
-        self.outputs.append(logits)
+            self._last_dims = (n, h, w)
+        # The reference appends one symbolic tensor per graph build (enet.py:405); this implementation is
+        # eager, so retaining every call's logits would grow device memory without bound (1.27 GB per batch
+        # of 8 at 1024x2048x19): only the most recent call is kept.
+        self.outputs = [logits]
         return logits
 
     call = __call__
@@ -191,9 +215,26 @@ class ENet:
         for off, shp in zip(offs, shapes):
             cnt = shp[0] * shp[1] * shp[2] * shp[3]
             views.append(ws[off:off + 4 * cnt].view(torch.float32).view(shp))
-        self._endpoints.append([final] + views)
-        if len(self._endpoints) > 4:  # views alias one workspace: keep the list short
-            self._endpoints = self._endpoints[-4:]
+        # the views alias one workspace that the next call overwrites: only the latest entry is meaningful
+        self._endpoints = [[final] + views]
+
+    def pooling_argmax(self):
+        """(argmax1 [n,h/4,w/4,16], argmax2 [n,h/8,w/8,64]) int64 of the most recent ``__call__`` / ``score``:
+        the indices ``ENet.call`` passes from the downsampling to the upsampling blocks (reference
+        enet.py:331,338,359,364), in the reference's per-image form ``(y*W + x)*C + c``."""
+        torch = _lib.require_gpu()
+        if self._last_dims is None:
+            raise RuntimeError("no forward pass has run yet")
+        n, h, w = self._last_dims
+        ws = self._ws
+        out = []
+        with torch.cuda.device(ws.device):
+            for which, (div, c) in ((1, (4, 16)), (2, (8, 64))):
+                a = torch.empty((n, h // div, w // div, c), dtype=torch.int64, device=ws.device)
+                _lib.check(_lib.lib().ssal_enet_export_argmax(self._handle, _lib.dev_ptr(ws), ws.numel(), n, h, w,
+                                                              which, _lib.dev_ptr(a), _lib.stream_ptr()))
+                out.append(a)
+        return tuple(out)
 
     # ---- fused pool scoring (active_learning.py:229-263) -----------------------------------
     def score(self, inputs, measure="entropy", threshold=0.0, return_label=False,
@@ -223,6 +264,7 @@ class ENet:
                 handle, _lib.dev_ptr(x), n, h, w, _lib.MEASURES[measure], float(threshold),
                 _lib.dev_ptr(scores, torch.float64, "scores"), _lib.dev_ptr(label), _lib.dev_ptr(mask),
                 _lib.dev_ptr(conf), _lib.dev_ptr(ws), ws.numel(), _lib.stream_ptr()))
+            self._last_dims = (n, h, w)
         if return_label or return_mask or return_confidence:
             return scores, {"label": label, "mask": mask, "confidence": conf}
         return scores
@@ -240,6 +282,7 @@ class ENet:
             name = layer.name.encode()
             nbytes = L.ssal_enet_layer_workspace_bytes(handle, name, n, h, w)
             ws = self._workspace(max(nbytes, 1024), x.device)
+            self._last_dims = None  # the single-layer call re-carves the workspace
             y = torch.empty(layer.output_shape(n, h, w), dtype=torch.float32, device=x.device)
             amax_out = None
             if want_argmax:

@@ -90,7 +90,7 @@ class Variable:
 
 
 class Layer:
-    """Common plumbing: weight registry in creation order + dispatch to the owning ENet handle."""
+    """Common plumbing: weight registry (Keras ordering of ``.variables``) + dispatch to the owning ENet handle."""
 
     def __init__(self, name):
         self.name = name
@@ -104,11 +104,29 @@ class Layer:
         return v
 
     @property
-    def variables(self):
-        return list(self._variables)
+    def trainable_weights(self):
+        return [v for v in self._variables if v.trainable]
+
+    @property
+    def non_trainable_weights(self):
+        return [v for v in self._variables if not v.trainable]
 
     @property
     def weights(self):
+        """TF-1.13 Keras order: ``trainable_weights + non_trainable_weights``, each group in creation
+        order -- i.e. the moving batch-norm ``mean`` / ``variance`` (created ``trainable=False``,
+        reference enet_modules.py:150-163, 384-397, ...) come LAST.  This is the order the reference's
+        positional weight copy ``val_net.layers[i].variables[j] <- train_net...`` walks
+        (active_learning.py:475-482), so a copy from a real ``tf_net`` lands on the right tensors."""
+        return self.trainable_weights + self.non_trainable_weights
+
+    @property
+    def variables(self):
+        return self.weights
+
+    @property
+    def creation_order_variables(self):
+        """the same variables in ``add_weight`` order (the seeded synthetic recipes draw in this order)"""
         return list(self._variables)
 
     # name -> Variable mapping in C-ABI naming ("<Layer>.<attr>")

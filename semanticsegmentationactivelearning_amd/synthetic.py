@@ -89,11 +89,11 @@ def _glorot(rng, shape):
 
 
 def randomize_enet(model, seed=0, final_gain=8.0):
-    """Fill every variable of a built ``models.ENet`` with the seeded synthetic recipe, in
-    ``model.variables`` order (deterministic for a given architecture)."""
+    """Fill every variable of a built ``models.ENet`` with the seeded synthetic recipe, layer by layer
+    in ``add_weight`` creation order (deterministic for a given architecture)."""
     rng = np.random.default_rng(seed)
     for layer in model.layers:
-        for var in layer.variables:
+        for var in layer.creation_order_variables:
             leaf = var.name.rsplit("/", 1)[-1]
             shape = var.shape
             if leaf.startswith("Kernel"):

@@ -85,6 +85,7 @@ class InputStage:
             raise ValueError("pin_buffers must be >= 2")
         self._pinned = []  # ring of page-locked image batch buffers (allocated lazily, reused)
         self._pin_pos = 0
+        self._pin_events = {}  # slot -> event of the async host-to-device copy still reading that slot
         if len(input_shape) == 3:
             self.shape = list(input_shape)
         elif len(input_shape) == 2:
@@ -179,22 +180,31 @@ class InputStage:
                 yield batch
 
     def _stack_pinned(self, images):
-        """np.stack(images) written into the next buffer of the page-locked ring -> CPU torch tensor"""
+        """np.stack(images) written into the next buffer of the page-locked ring -> CPU torch tensor.
+
+        A consumer that copies the batch to the GPU asynchronously (``active_learning.prefetch_to_device``) hands
+        the copy-done event back through the tensor's ``_ssal_copy_issued`` hook; a slot is never rewritten on
+        the host while a DMA read of it is still in flight."""
         import torch
         shape = (len(images),) + tuple(images[0].shape)
         dtype = torch.uint8 if images[0].dtype == np.uint8 else torch.float32
         need = int(np.prod(shape))
-        if len(self._pinned) < self.pin_buffers:
-            self._pinned.append(torch.empty(need, dtype=dtype, pin_memory=True))
-            buf = self._pinned[-1]
-        else:
-            k = self._pin_pos % self.pin_buffers
-            if self._pinned[k].numel() < need or self._pinned[k].dtype != dtype:
-                self._pinned[k] = torch.empty(need, dtype=dtype, pin_memory=True)
-            buf = self._pinned[k]
+        slot = self._pin_pos % self.pin_buffers
         self._pin_pos += 1
-        out = buf[:need].view(shape)
+        if slot >= len(self._pinned):
+            self._pinned.append(torch.empty(need, dtype=dtype, pin_memory=True))
+        ev = self._pin_events.pop(slot, None)
+        if ev is not None:
+            ev.synchronize()  # the previous batch in this slot has left for the GPU
+        if self._pinned[slot].numel() < need or self._pinned[slot].dtype != dtype:
+            self._pinned[slot] = torch.empty(need, dtype=dtype, pin_memory=True)
+        out = self._pinned[slot][:need].view(shape)
         np.stack(images, out=out.numpy())
+        events = self._pin_events
+
+        def _copy_issued(event, _slot=slot):
+            events[_slot] = event
+        out._ssal_copy_issued = _copy_issued
         return out
 
     # ---- per-example work -------------------------------------------------------------------------

@@ -664,3 +664,154 @@ def test_forward_c5_medium_rgb_nir(enet_c4k6):
     scores, extra = net.score(dev(x), "entropy", return_label=True)
     report_diff("C5 label", extra["label"].cpu().numpy(), want_label)
     report_diff("C5 mean", scores.cpu().numpy(), want_mean, exact=False, atol=1e-6)
+
+
+# ---- round 2: parity hardening -------------------------------------------------------------------
+def test_whole_network_pooling_indices_match_golden_and_oracle(enet_c3k19, enet_c4k6):
+    """the max-pooling indices ENet.call hands from the downsample to the upsample blocks (enet.py:331,338), exported
+    from the whole-network run in the reference's int64 form, bit-exact against the golden fixtures and the oracle"""
+    for (net, P), fx, hw, c in ((enet_c3k19, "enet_c3k19_64x128.npz", (64, 128), 3),
+                                (enet_c4k6, "enet_c4k6_64x64.npz", (64, 64), 4)):
+        g = np.load(os.path.join(GOLDEN, fx))
+        x = frames(list(g["frame_ids"]), hw[0], hw[1], c)
+        net(dev(x), training=False)
+        a1, a2 = net.pooling_argmax()
+        assert a1.dtype == torch.int64 and a2.dtype == torch.int64
+        report_diff(fx + " argmax1", a1.cpu().numpy(), g["argmax1"])
+        report_diff(fx + " argmax2", a2.cpu().numpy(), g["argmax2"])
+        net.score(dev(x), "entropy")  # the score path saves the same indices
+        b1, b2 = net.pooling_argmax()
+        assert torch.equal(a1, b1) and torch.equal(a2, b2)
+    net, P = enet_c3k19
+    x = frames([11, 12], 72, 40, 3)
+    ep = {}
+    orc.enet_forward(P, x, ep)
+    net(dev(x), training=False)
+    a1, a2 = net.pooling_argmax()
+    report_diff("argmax1 vs oracle", a1.cpu().numpy(), ep["argmax1"])
+    report_diff("argmax2 vs oracle", a2.cpu().numpy(), ep["argmax2"])
+
+
+@pytest.mark.parametrize("measure", ["entropy", "margin", "confidence"])
+def test_score_edge_vectors(measure):
+    """logit gaps beyond exp underflow (p == 0), exact two-way / K-way ties, K = 2, and a threshold exactly equal to
+    a pixel's confidence"""
+    K = 19
+    lg = np.zeros((1, 4, 8, K), np.float32)
+    lg[0, 0, 0] = -300.0; lg[0, 0, 0, 7] = 50.0          # one-hot: every other p underflows to exactly 0
+    lg[0, 0, 1] = -120.0; lg[0, 0, 1, 3] = 0.0; lg[0, 0, 1, 9] = 0.0   # two-way tie, rest underflow
+    lg[0, 0, 2] = 2.5                                     # K-way tie
+    lg[0, 0, 3, :] = np.linspace(-150, 10, K)             # mixed: half of the classes underflow
+    lg[0, 0, 4, 0] = 88.0; lg[0, 0, 4, 1] = -88.0         # gap 176 with finite exp on one side only
+    lg[0, 0, 5, 5] = 1.0; lg[0, 0, 5, 6] = 1.0; lg[0, 0, 5, 7] = 1.0   # three-way tie above a floor
+    lg[0, 1] = (np.random.default_rng(3).normal(size=(8, K)) * 30).astype(np.float32)
+    want_mean, want_conf, want_label = orc.score_logits(lg, measure)
+    assert np.isfinite(want_conf).all()
+    scores, extra = al.score_logits(dev(lg), measure, return_label=True, return_confidence=True)
+    conf = extra["confidence"].cpu().numpy()
+    report_diff("label", extra["label"].cpu().numpy(), want_label)
+    report_diff("confidence", conf, want_conf, exact=False, atol=TOL)  # north_star: 1e-4
+    report_diff("mean", scores.cpu().numpy(), want_mean, exact=False, atol=1e-6)
+    # exact values where the mathematics is exact
+    if measure == "margin":
+        assert conf[0, 0, 0] == 1.0 and conf[0, 0, 1] == 0.0 and conf[0, 0, 2] == 0.0 and conf[0, 0, 5] == 0.0
+    if measure == "confidence":
+        assert conf[0, 0, 0] == 1.0 and conf[0, 0, 1] == 0.5 and abs(conf[0, 0, 2] - 1.0 / K) < 1e-7
+    if measure == "entropy":
+        assert conf[0, 0, 0] == 1.0 and abs(conf[0, 0, 2]) < 1e-6
+    assert extra["label"][0, 0, 1].item() == 3 and extra["label"][0, 0, 2].item() == 0  # first maximum wins
+    # threshold == a pixel's own confidence: `conf < threshold ? 0 : 1` keeps it (active_learning.py:265-269)
+    thr = float(conf[0, 1, 2])
+    _, e2 = al.score_logits(dev(lg), measure, threshold=thr, return_mask=True, return_confidence=True)
+    mask = e2["mask"].cpu().numpy()
+    assert mask[0, 1, 2] == 1
+    assert (mask == (conf >= np.float32(thr))).all()
+    # K = 2
+    l2 = np.array([[[[0.0, 0.0], [200.0, -200.0], [-1.0, 1.0], [3.0, 3.0000002]]]], np.float32)
+    wm, wc, wl = orc.score_logits(l2, measure)
+    s2, x2 = al.score_logits(dev(l2), measure, return_label=True, return_confidence=True)
+    report_diff("K=2 label", x2["label"].cpu().numpy(), wl)
+    report_diff("K=2 conf", x2["confidence"].cpu().numpy(), wc, exact=False, atol=TOL)
+
+
+def test_score_nonfinite_policy():
+    """-inf logits behave like exp underflow (p = 0, finite confidence, equal to the oracle's); NaN or +inf logits
+    give a NaN confidence for that pixel (like tf.nn.softmax), the image mean is NaN and ranking puts it last"""
+    K = 6
+    rng = np.random.default_rng(8)
+    lg = (rng.normal(size=(2, 4, 4, K)) * 3).astype(np.float32)
+    lg[0, 1, 1, 2] = -np.inf
+    lg[0, 2, 2, :] = -np.inf
+    lg[0, 2, 2, 4] = 0.5
+    for m in ("entropy", "margin", "confidence"):
+        want_mean, want_conf, want_label = orc.score_logits(lg, m)
+        assert np.isfinite(want_conf).all()
+        s, e = al.score_logits(dev(lg), m, return_label=True, return_confidence=True)
+        report_diff(m + " conf with -inf logits", e["confidence"].cpu().numpy(), want_conf, exact=False, atol=TOL)
+        report_diff(m + " label", e["label"].cpu().numpy(), want_label)
+        assert e["confidence"][0, 2, 2].item() == 1.0
+    bad = lg.copy()
+    bad[1, 0, 0, 1] = np.nan
+    bad[1, 3, 3, 0] = np.inf
+    for m in ("entropy", "margin", "confidence"):
+        s, e = al.score_logits(dev(bad), m, return_confidence=True)
+        c = e["confidence"].cpu().numpy()
+        assert np.isnan(c[1, 0, 0]) and np.isnan(c[1, 3, 3])
+        assert np.isfinite(c[0]).all() and np.isfinite(np.delete(c[1].ravel(), [0, 15])).all()
+        sc = s.cpu().numpy()
+        assert np.isfinite(sc[0]) and np.isnan(sc[1])
+        low, _ = al.finish_ranking(np.arange(2), sc, 2, np.arange(2), 1)
+        assert low.tolist() == [0]  # NaN never ranks as "least confident"
+
+
+def test_spatial_dropout_op():
+    """xops.spatial_dropout (extra_ops.py:137-151): whole (image, channel) planes are either zero or scaled by
+    1/(1-rate); exact against the host twin of the seeded draw; deterministic; keep ratio ~ 1-rate"""
+    rng = np.random.default_rng(2)
+    for (n, h, w, c), rate in (((3, 6, 10, 64), 0.1), ((2, 5, 7, 19), 0.5), ((1, 4, 4, 128), 0.01)):
+        x = (rng.normal(size=(n, h, w, c)) + 3.0).astype(np.float32)
+        y = xops.spatial_dropout(dev(x), rate, seed=77).cpu().numpy()
+        keep = xops.spatial_dropout_keep_mask(n, c, rate, seed=77)
+        want = (x / np.float32(1.0 - rate)) * keep[:, None, None, :]
+        report_diff("spatial_dropout", y, want)
+        per_plane = (y != 0).reshape(n, h * w, c)
+        assert (per_plane.all(axis=1) | (~per_plane).any(axis=1) == True).all()
+        assert ((per_plane.all(axis=1)) == (keep == 1)).all() and ((~per_plane).all(axis=1) == (keep == 0)).all()
+        y2 = xops.spatial_dropout(dev(x), rate, seed=77).cpu().numpy()
+        assert np.array_equal(y, y2)
+        y3 = xops.spatial_dropout(dev(x), rate, seed=78).cpu().numpy()
+        assert rate < 0.05 or not np.array_equal(y, y3)
+    keep = xops.spatial_dropout_keep_mask(64, 128, 0.3, seed=5)
+    assert abs(keep.mean() - 0.7) < 0.02
+    assert np.array_equal(xops.spatial_dropout(dev(x), 0.0).cpu().numpy(), x)
+    with pytest.raises(ValueError):
+        xops.spatial_dropout(dev(x), 1.0)
+
+
+def test_repeated_calls_do_not_grow_device_memory(enet_c3k19):
+    """ENet.__call__ keeps only the most recent logits / endpoints (an eager stand-in for the reference's
+    once-per-graph-build `outputs.append`, enet.py:405): memory stays flat over many calls"""
+    net, _ = enet_c3k19
+    x = syn.synth_frames_device(0, 2, 64, 128, 3)
+    for _ in range(3):
+        net(x, training=False)
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    for _ in range(200):
+        net(x, training=False)
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_allocated() <= base + (1 << 20)
+    assert len(net.outputs) == 1 and len(net.endpoint_outputs) == 1
+
+
+def test_knobs_are_reported_and_default():
+    k = _lib.get_knobs()
+    assert k["defaults"] == 1 and k["measure_build"] == 0 and k["ablate"] == 0 and "MEASUREMENT" not in k["version"]
+    with pytest.raises(ValueError):
+        _lib.set_knob("ablate", 1)  # no work-skipping switch in the product build
+    _lib.set_knob("bnk_tw", 16)
+    try:
+        assert _lib.get_knobs()["defaults"] == 0
+    finally:
+        _lib.set_knob("bnk_tw", 0)
+    assert _lib.get_knobs()["defaults"] == 1

@@ -98,11 +98,85 @@ def test_parameter_count_and_layouts(classes, c_in, count):
     assert net.Bottleneck4_0.res_kernel.shape == (1, 1, 128, 64)
     assert net.Bottleneck5_0.exp_kernel.shape == (1, 1, 8, 16)
     assert net.Final.kernel.shape == (3, 3, classes, 16)
-    # reference creation order of a Bottleneck's variables (enet_modules.py:366-523)
-    leafs = [v.name.split("/", 1)[1] for v in net.Bottleneck1_1.variables]
-    assert leafs[:6] == ["Projection/Kernel", "Projection/Alpha", "Projection/BatchNorm/Mean",
-                         "Projection/BatchNorm/Variance", "Projection/BatchNorm/Gamma", "Projection/BatchNorm/Beta"]
-    assert leafs[-1] == "Residual/Alpha" and len(leafs) == 18
+    assert len(net.Bottleneck1_1.variables) == 18
+
+
+# Keras (TF 1.13) `Layer.variables` == `Layer.weights` == trainable_weights + non_trainable_weights, each group in
+# add_weight order.  The lists below are written out from the reference's `trainable=` flags
+# (models/enet/enet_modules.py:139-187 Initial, 366-523 Bottleneck, 1070-1214 BottleneckUpsample, 1349-1356 Final):
+# the moving batch-norm Mean / Variance (trainable=False) come last.
+_BN_T = ["BatchNorm/Gamma", "BatchNorm/Beta"]
+_BN_N = ["BatchNorm/Mean", "BatchNorm/Variance"]
+KERAS_ORDER = {
+    "Initial": ["Convolution/Kernel", "Convolution/BatchNorm/Gamma", "Convolution/BatchNorm/Beta", "Residual/Alpha",
+                "Convolution/BatchNorm/Mean", "Convolution/BatchNorm/Variance"],
+    "Bottleneck1_1": ["Projection/Kernel", "Projection/Alpha"] + ["Projection/" + t for t in _BN_T]
+                     + ["Convolution/Kernel", "Convolution/Alpha"] + ["Convolution/" + t for t in _BN_T]
+                     + ["Expansion/Kernel"] + ["Expansion/" + t for t in _BN_T] + ["Residual/Alpha"]
+                     + ["Projection/" + t for t in _BN_N] + ["Convolution/" + t for t in _BN_N]
+                     + ["Expansion/" + t for t in _BN_N],
+    "Bottleneck2_3": ["Projection/Kernel", "Projection/Alpha"] + ["Projection/" + t for t in _BN_T]
+                     + ["Convolution/KernelCol", "Convolution/KernelRow", "Convolution/Alpha"]
+                     + ["Convolution/" + t for t in _BN_T]
+                     + ["Expansion/Kernel"] + ["Expansion/" + t for t in _BN_T] + ["Residual/Alpha"]
+                     + ["Projection/" + t for t in _BN_N] + ["Convolution/" + t for t in _BN_N]
+                     + ["Expansion/" + t for t in _BN_N],
+    "Bottleneck4_0": ["Projection/Kernel", "Projection/Alpha"] + ["Projection/" + t for t in _BN_T]
+                     + ["Convolution/Kernel", "Convolution/Alpha"] + ["Convolution/" + t for t in _BN_T]
+                     + ["Expansion/Kernel"] + ["Expansion/" + t for t in _BN_T]
+                     + ["Residual/Kernel", "Residual/Alpha"]
+                     + ["Projection/" + t for t in _BN_N] + ["Convolution/" + t for t in _BN_N]
+                     + ["Expansion/" + t for t in _BN_N],
+    "Final": ["Kernel"],
+}
+
+
+@pytest.mark.parametrize("layer", sorted(KERAS_ORDER))
+def test_layer_variables_follow_the_keras_order(layer):
+    net = ssal.ENet(19)
+    net.build((None, None, None, 3))
+    L = getattr(net, layer)
+    leafs = [v.name.split("/", 1)[1] for v in L.variables]
+    assert leafs == KERAS_ORDER[layer]
+    assert [v.name for v in L.weights] == [v.name for v in L.variables]
+    assert all(v.trainable for v in L.trainable_weights) and not any(v.trainable for v in L.non_trainable_weights)
+    # creation order stays available (the seeded synthetic recipe draws in it)
+    assert sorted(v.name for v in L.creation_order_variables) == sorted(v.name for v in L.variables)
+    if layer == "Initial":
+        assert [v.name.split("/", 1)[1] for v in L.creation_order_variables][:3] == \
+            ["Convolution/Kernel", "Convolution/BatchNorm/Mean", "Convolution/BatchNorm/Variance"]
+
+
+def test_positional_copy_from_a_tf_ordered_list():
+    """A list laid out like TF's `Initial.variables` ([kernel, gamma, beta, alpha, mean, variance]) copied
+    positionally (active_learning.py:475-482) must land gamma in gamma and variance in variance."""
+    net = ssal.ENet(19)
+    net.build((None, None, None, 3))
+    rng = np.random.default_rng(0)
+    src = {"kernel": rng.normal(size=(3, 3, 3, 13)), "gamma": rng.uniform(0.8, 1.2, 16), "beta": rng.normal(size=16),
+           "alpha": rng.uniform(0.1, 0.4, 16), "mean": rng.normal(size=16), "variance": rng.uniform(0.5, 1.5, 16)}
+    tf_list = [src[k] for k in ("kernel", "gamma", "beta", "alpha", "mean", "variance")]
+    for dst, val in zip(net.Initial.variables, tf_list):
+        dst.assign(val)
+    for k, v in src.items():
+        assert np.array_equal(getattr(net.Initial, k).numpy(), v.astype(np.float32)), k
+    assert (net.Initial.variance.numpy() > 0).all()
+
+
+def test_name_keyed_weight_copy():
+    a, b = ssal.ENet(19), ssal.ENet(19)
+    a.build((None, None, None, 3))
+    b.build((None, None, None, 3))
+    syn.randomize_enet(a, seed=5)
+    named = {"ENet/%s:0" % v.name: v.numpy().copy() for v in a.variables}  # TF-style names
+    assert b.assign_named(named) == len(a.variables)
+    pa, pb = syn.enet_params_dict(a), syn.enet_params_dict(b)
+    assert all((pa[k] == pb[k]).all() for k in pa)
+    with pytest.raises(KeyError):
+        b.assign_named({"ENet/Initial/NoSuchThing:0": np.zeros(3)})
+    del named["ENet/Final/Kernel:0"]
+    with pytest.raises(KeyError):
+        b.assign_named(named, strict=True)
 
 
 def test_positional_weight_copy_between_models():

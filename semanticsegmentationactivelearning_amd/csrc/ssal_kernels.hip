@@ -349,11 +349,11 @@ __device__ __forceinline__ float pixel_score(const float (&l)[K], int measure, f
     float S = 0.0f, T = 0.0f, e2 = 0.0f;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        // -inf logits (p = 0 exactly, like the reference's softmax): keep 0 * d finite so T stays a number
-        const float d = fmaxf(l[k] - m, -3.0e38f);
-        const float e = __expf(d);
+        const float d = l[k] - m;
+        const float e = __expf(d);  // NaN (NaN logit, or inf - inf) propagates into S and from there into every measure
         S += e;
-        T = fmaf(e, d, T);
+        // -inf logits (p = 0 exactly, like the reference's softmax): keep 0 * d finite so T stays a number
+        T = fmaf(e, fmaxf(d, -3.0e38f), T);
         if (k != am && e > e2) e2 = e;
     }
     if (measure == 0) {

@@ -132,8 +132,6 @@ def test_prelu_and_batch_norm_ops():
     report_diff("batch_norm", out.cpu().numpy(), orc.affine_prelu(x, s, t, None))
     with pytest.raises(NotImplementedError):
         xops.batch_norm(dev(x), dev(m), dev(v), dev(g), dev(b), training=True)
-    with pytest.raises(NotImplementedError):
-        xops.spatial_dropout(dev(x), 0.1)
 
 
 def test_resize_bilinear_tf113_legacy_mapping():

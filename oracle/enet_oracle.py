@@ -28,8 +28,8 @@ _f32p = ctypes.POINTER(ctypes.c_float)
 def build(force=False):
     """gcc-compile the C restatement (content-stamped: mtimes do not survive a snapshot copy)"""
     import hashlib
-    src = os.path.join(_HERE, "enet_oracle.c")
-    digest = hashlib.sha256(open(src, "rb").read() + open(os.path.join(_HERE, "Makefile"), "rb").read()).hexdigest()
+    digest = hashlib.sha256(b"".join(open(os.path.join(_HERE, f), "rb").read()
+                                     for f in ("enet_oracle.c", "icnet_oracle.c", "Makefile"))).hexdigest()
     stamp = _SO + ".stamp"
     fresh = os.path.exists(_SO) and os.path.exists(stamp) and open(stamp).read().strip() == digest
     if force or not fresh:

@@ -178,3 +178,99 @@ def score_images(P, x_nhwc, measure="entropy"):
     logits = enet_forward(P, x_nhwc)
     mean, conf, label = score_logits(logits, measure)
     return mean, conf, label, logits
+
+
+# ====================================================================================================
+# ICNet (ICNET_SPEC.md) -- independent restatement on stock torch-CPU ops.  There is no reference behaviour for
+# this network (models/icnet/icnet.py:1-7 is an empty class): "parity unpinned AND undefined".
+# ====================================================================================================
+def resize_bilinear_legacy(x, oh, ow):
+    """tf.image.resize_bilinear, TF-1.13 defaults (align_corners=False, src = dst * in/out, no half-pixel offset)
+    on an NCHW tensor -- torch's own interpolate() uses half-pixel centres, so the gather is written out."""
+    n, c, h, w = x.shape
+    fy = torch.arange(oh, dtype=torch.float32) * (float(h) / float(oh))
+    fx = torch.arange(ow, dtype=torch.float32) * (float(w) / float(ow))
+    y0, x0 = fy.floor().long(), fx.floor().long()
+    y1, x1 = torch.clamp(y0 + 1, max=h - 1), torch.clamp(x0 + 1, max=w - 1)
+    ly = (fy - y0.float()).view(1, 1, oh, 1)
+    lx = (fx - x0.float()).view(1, 1, 1, ow)
+    top = x[:, :, y0][:, :, :, x0] + (x[:, :, y0][:, :, :, x1] - x[:, :, y0][:, :, :, x0]) * lx
+    bot = x[:, :, y1][:, :, :, x0] + (x[:, :, y1][:, :, :, x1] - x[:, :, y1][:, :, :, x0]) * lx
+    return top + (bot - top) * ly
+
+
+def max_pool_3x3_s2_same(x):
+    h, w = x.shape[2:]
+    pt, pb = _same_pad(h, 3, 2, 1)
+    pl, pr = _same_pad(w, 3, 2, 1)
+    return F.max_pool2d(F.pad(x, (pl, pr, pt, pb), value=float("-inf")), 3, 2)
+
+
+def _ic_conv_bn(P, nm, x, stride=1, dil=1, relu=True, res=None):
+    y = batch_norm(conv2d_same(x, P[nm + ".kernel"], stride=stride, dil=dil), P, nm + ".")
+    if res is not None:
+        y = y + res
+    return F.relu(y) if relu else y
+
+
+def _ic_bottleneck(P, nm, x, stride, dil, proj):
+    sc = _ic_conv_bn(P, nm + "_1x1_proj", x, stride=stride, relu=False) if proj else x
+    y = _ic_conv_bn(P, nm + "_1x1_reduce", x, stride=stride)
+    y = _ic_conv_bn(P, nm + "_3x3", y, dil=dil)
+    return _ic_conv_bn(P, nm + "_1x1_increase", y, relu=True, res=sc)
+
+
+_IC_BNECKS = ([("conv2_1", 1, 1, True), ("conv2_2", 1, 1, False), ("conv2_3", 1, 1, False), ("conv3_1", 2, 1, True)]
+              + [("conv3_%d" % i, 1, 1, False) for i in (2, 3, 4)] + [("conv4_1", 1, 2, True)]
+              + [("conv4_%d" % i, 1, 2, False) for i in (2, 3, 4, 5, 6)] + [("conv5_1", 1, 4, True)]
+              + [("conv5_%d" % i, 1, 4, False) for i in (2, 3)])
+
+
+def icnet_forward(P, x_nhwc, endpoints=None, full_logits=True):
+    """ICNET_SPEC.md sections 1-4 -> logits NHWC numpy"""
+    with torch.no_grad():
+        x = _t(x_nhwc).permute(0, 3, 1, 2).contiguous()
+        n, _, h, w = x.shape
+        ep = endpoints if endpoints is not None else {}
+        y = resize_bilinear_legacy(x, h // 2, w // 2)
+        y = _ic_conv_bn(P, "conv1_1_3x3_s2", y, stride=2)
+        y = _ic_conv_bn(P, "conv1_2_3x3", y)
+        y = _ic_conv_bn(P, "conv1_3_3x3", y)
+        y = max_pool_3x3_s2_same(y)
+        for nm, s, d, proj in _IC_BNECKS[:4]:
+            y = _ic_bottleneck(P, nm, y, s, d, proj)
+        f2 = y
+        y = resize_bilinear_legacy(f2, h // 32, w // 32)
+        for nm, s, d, proj in _IC_BNECKS[4:]:
+            y = _ic_bottleneck(P, nm, y, s, d, proj)
+        ep["conv5_3"] = y
+        hh, ww = y.shape[2:]
+        acc = y
+        for b in (1, 2, 3, 6):
+            acc = acc + resize_bilinear_legacy(F.adaptive_avg_pool2d(y, b), hh, ww)
+        ep["conv5_3_sum"] = acc
+        f1 = _ic_conv_bn(P, "conv5_4_k1", acc)
+        y = _ic_conv_bn(P, "conv1_sub1", x, stride=2)
+        y = _ic_conv_bn(P, "conv2_sub1", y, stride=2)
+        f3 = _ic_conv_bn(P, "conv3_sub1", y, stride=2)
+        up = resize_bilinear_legacy(f1, 2 * f1.shape[2], 2 * f1.shape[3])
+        s24 = _ic_conv_bn(P, "conv_sub4", up, dil=2, relu=True, res=_ic_conv_bn(P, "conv3_1_sub2_proj", f2, relu=False))
+        ep["sub24_sum"] = s24
+        up = resize_bilinear_legacy(s24, 2 * s24.shape[2], 2 * s24.shape[3])
+        s12 = _ic_conv_bn(P, "conv_sub2", up, dil=2, relu=True, res=_ic_conv_bn(P, "conv3_sub1_proj", f3, relu=False))
+        ep["sub12_sum"] = s12
+        y = resize_bilinear_legacy(s12, h // 4, w // 4)
+        y = conv2d_same(y, P["conv6_cls.kernel"]) + _t(P["conv6_cls.bias"]).view(1, -1, 1, 1)
+        ep["conv6_cls"] = y
+        for k in list(ep):
+            if isinstance(ep[k], torch.Tensor):
+                ep[k] = ep[k].permute(0, 2, 3, 1).contiguous().numpy()
+        if full_logits:
+            y = resize_bilinear_legacy(y, h, w)
+        return y.permute(0, 2, 3, 1).contiguous().numpy()
+
+
+def icnet_score_images(P, x_nhwc, measure="margin"):
+    logits = icnet_forward(P, x_nhwc)
+    mean, conf, label = score_logits(logits, measure)
+    return mean, conf, label, logits

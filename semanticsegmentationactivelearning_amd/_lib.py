@@ -19,7 +19,7 @@ MEASURES = {"entropy": 0, "margin": 1, "confidence": 2}
 _c = ctypes
 _vp, _i, _i64, _f = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float
 
-# symbol -> (restype, argtypes); one row per declaration in include/ssal_enet.h
+# symbol -> (restype, argtypes); one row per declaration in include/ssal_enet.h and include/ssal_icnet.h
 PROTOTYPES = {
     "ssal_version": (_c.c_char_p, []),
     "ssal_last_error": (_c.c_char_p, []),
@@ -59,6 +59,29 @@ PROTOTYPES = {
     "ssal_debug_set_knob": (_i, [ctypes.c_char_p, _i]),
     "ssal_debug_get_knobs": (_i, [_c.c_char_p, _i64]),
     "ssal_debug_copy_probe": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    # ---- include/ssal_icnet.h ----
+    "ssal_icnet_create": (_i, [_i, _i, _c.POINTER(_vp)]),
+    "ssal_icnet_destroy": (_i, [_vp]),
+    "ssal_icnet_num_tensors": (_i, [_vp]),
+    "ssal_icnet_tensor_info": (_i, [_vp, _i, _c.POINTER(_c.c_char_p), _c.POINTER(_i), _c.POINTER(_i64)]),
+    "ssal_icnet_set_tensor": (_i, [_vp, _c.c_char_p, _vp, _i64]),
+    "ssal_icnet_commit": (_i, [_vp, _vp]),
+    "ssal_icnet_workspace_bytes": (_i64, [_vp, _i, _i, _i]),
+    "ssal_icnet_forward_nhwc": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i64, _vp]),
+    "ssal_icnet_forward_nhwc_u8": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i64, _vp]),
+    "ssal_icnet_score_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "ssal_icnet_score_nhwc_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "ssal_icnet_num_endpoints": (_i, [_vp]),
+    "ssal_icnet_endpoint_name": (_i, [_vp, _i, _c.POINTER(_c.c_char_p)]),
+    "ssal_icnet_endpoint_info": (_i, [_vp, _c.c_char_p, _i, _i, _i, _c.POINTER(_i64), _c.POINTER(_i64)]),
+    "ssal_conv_bn_workspace_bytes": (_i64, [_i, _i, _i, _i]),
+    "ssal_conv_bn_act": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
+                              _vp, _vp, _i64, _vp]),
+    "ssal_max_pool_3x3_s2": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "ssal_pyramid_pooling": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i64, _vp]),
+    "ssal_upscore_workspace_bytes": (_i64, [_i, _i, _i]),
+    "ssal_upscore_logits_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    # ---- measurement aids (include/ssal_enet.h) ----
     "ssal_profile_enable": (_i, [_i]),
     "ssal_profile_collect": (_i, [_c.c_char_p, _i64]),
 }

@@ -2,6 +2,7 @@
 // sequencing.  Host C++ only; no torch types.  gfx950 (MI355X) only.
 #include "../../include/ssal_enet.h"
 #include "ssal_internal.h"
+#include "ssal_host.h"
 #include "ssal_prof.h"
 
 #include <math.h>
@@ -15,14 +16,14 @@
 
 using namespace ssal;
 
-#define SSAL_API extern "C" __attribute__((visibility("default")))
 
 // ------------------------------------------------------------------------------------------------
 // error reporting
 // ------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 
-static int fail(int code, const char *fmt, ...)
+namespace ssal {
+int fail(int code, const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
@@ -30,13 +31,7 @@ static int fail(int code, const char *fmt, ...)
     va_end(ap);
     return code;
 }
-
-#define HIP_TRY(expr)                                                                   \
-    do {                                                                                \
-        hipError_t e_ = (expr);                                                         \
-        if (e_ != hipSuccess)                                                           \
-            return fail(SSAL_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_));      \
-    } while (0)
+}  // namespace ssal
 
 SSAL_API const char *ssal_version(void) { 
 #ifdef SSAL_MEASURE
@@ -92,19 +87,6 @@ static const LayerSpec kSpecs[] = {
     {"Final", K_FINAL, 0, 1, false},
 };
 static const int kNumLayers = (int)(sizeof(kSpecs) / sizeof(kSpecs[0]));
-
-struct HostTensor {
-    std::string name;
-    std::vector<int64_t> dims;
-    std::vector<float> data;
-    bool set = false;
-    int64_t numel() const
-    {
-        int64_t n = 1;
-        for (auto d : dims) n *= d;
-        return n;
-    }
-};
 
 // device-side view of one layer after commit
 struct DevLayer {
@@ -273,18 +255,6 @@ SSAL_API int ssal_enet_set_tensor(ssal_enet *net, const char *name, const float 
 
 // ---- commit: fold BN, re-layout transposed kernels, upload one arena ---------------------------
 namespace {
-struct ArenaBuilder {
-    std::vector<float> host;
-    size_t push(const float *p, size_t n)
-    {
-        size_t off = (host.size() + 63) / 64 * 64;  // 256-B alignment
-        host.resize(off + n);
-        memcpy(host.data() + off, p, n * sizeof(float));
-        return off;
-    }
-    size_t push(const std::vector<float> &v) { return push(v.data(), v.size()); }
-};
-
 const std::vector<float> &T(const ssal_enet *h, const std::string &name)
 {
     return h->tensors[h->index.at(name)].data;
@@ -469,21 +439,6 @@ SSAL_API int ssal_enet_commit(ssal_enet *net, void *stream)
 // workspace carving
 // ------------------------------------------------------------------------------------------------
 namespace {
-struct Bump {
-    char *base;
-    int64_t cap, off = 0;
-    bool ok = true;
-    Bump(void *b, int64_t c) : base((char *)b), cap(c) {}
-    template <typename Tp> Tp *take(int64_t count)
-    {
-        int64_t o = (off + 255) / 256 * 256;
-        int64_t bytes = count * (int64_t)sizeof(Tp);
-        off = o + bytes;
-        if (base && off > cap) ok = false;
-        return base ? (Tp *)(base + o) : nullptr;
-    }
-};
-
 struct LayerTemps {
     float *t0, *t1, *t2, *t3;
 };

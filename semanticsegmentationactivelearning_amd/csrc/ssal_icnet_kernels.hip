@@ -1,0 +1,575 @@
+// ssal_icnet_kernels.hip -- HIP kernels of the ICNet row (ICNET_SPEC.md), gfx950 (MI355X / CDNA4) only.
+//
+//   k_igemm<NT>      every convolution with Cin % 32 == 0: implicit GEMM on the fp32 matrix cores
+//                    (v_mfma_f32_32x32x2_f32), fused folded batch-norm + shortcut add + ReLU epilogue,
+//                    optional on-the-fly 2x bilinear up-sampling of its input (cascade feature fusion)
+//   k_conv_first     3x3 / stride-2 first convolution of a branch on the 1/3/4-channel image (VALU, HBM-bound)
+//   k_maxpool3x3_s2, k_ppm_pool, k_ppm_sum
+//   k_upscore<K>     conv6_interp (4x bilinear) + softmax + entropy / margin / confidence + fp64 block partials:
+//                    the full-resolution logits never reach HBM
+//
+// Bit-exactness contract (same as the ENet kernels): every conv output element is ONE fp32 fmaf chain over
+// (kh, kw, ci) ascending -- the fp32 MFMA is exactly such a chain over its k index -- so results equal the parity
+// oracle bit for bit.  Out-of-image taps contribute fmaf(0, w, acc) == acc.
+#include "ssal_icnet.h"
+#include "ssal_mfma.h"
+#include "ssal_prof.h"
+#include "ssal_score.h"
+
+#include <float.h>
+#include <string.h>
+
+namespace ssal {
+
+static inline int cdiv_i(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ------------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution on the fp32 matrix cores.
+//   D[pixel][cout] = sum_k A[pixel][k] * B[k][cout],  k = (kh*KW + kw)*Cin + ci  ascending.
+// Workgroup = 4 waves, tile = 128 pixels x 32*NT couts; wave w owns pixel rows [32w, 32w+32) and all 32*NT columns
+// (NT accumulator tiles of 32x32).  K is walked in chunks of 32 input channels of one tap: the A chunk is 128 pixels
+// x 128 B (one full line per pixel, coalesced), the B chunk is 32*NT rows x 128 B, contiguous in the re-laid-out
+// kernel [tap][Cin/32][CoutP][32].  Both go global -> registers -> LDS (two buffers: the loads of chunk t+1 are in
+// flight while chunk t is multiplied), rows padded to 36 floats so that the ds_read_b128 fragment reads
+// (lane = row, 4 consecutive k per lane half) are bank-conflict free.  A lane's float4 holds k = 4h..4h+3 of an
+// 8-k group; v_permlane32_swap re-pairs the registers into the (k, k+1) lane-half pairs the MFMA consumes, in
+// ascending k order (ssal_mfma.h), so no LDS transpose is needed.
+// ------------------------------------------------------------------------------------------------
+constexpr int IG_BM = 128, IG_LDK = 36;
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
+{
+    constexpr int BM = IG_BM, BN = 32 * NT, LDK = IG_LDK;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    int tile = blockIdx.x;
+    if (a.xcd_chunk) {
+        tile = (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3);
+        if (tile >= a.ntiles) return;  // whole workgroup, before any barrier
+    }
+    const int tn = tile % a.tiles_n, tm = tile / a.tiles_n;
+    const long m0 = (long)tm * BM;
+    const int n0 = tn * BN;
+
+    // ---- per-thread A rows: (tid >> 3) + 32 i, channel quad tid & 7 ------------------------------
+    const int col4 = tid & 7;
+    int iyb[4], ixb[4];
+    long nb[4];
+    bool mv[4];
+    const int Hs = a.up2 ? a.H >> 1 : a.H, Ws = a.up2 ? a.W >> 1 : a.W;  // dims of the tensor in memory
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long m = m0 + (tid >> 3) + 32 * i;
+        mv[i] = m < a.M;
+        const long mm = mv[i] ? m : 0;
+        const int ox = (int)(mm % a.Wo);
+        const long t = mm / a.Wo;
+        const int oy = (int)(t % a.Ho);
+        const long n = t / a.Ho;
+        iyb[i] = oy * a.stride - a.pad_t;
+        ixb[i] = ox * a.stride - a.pad_l;
+        nb[i] = n * (long)Hs * Ws;
+    }
+    const int cpt = a.Cin >> 5;             // chunks per tap
+    const int nchunks = a.KH * a.KW * cpt;
+
+    float4 ra[4], rb[NT];
+    auto gload = [&](int t) {
+        const int tap = t / cpt, cc = t - tap * cpt;
+        const int kh = tap / a.KW, kw = tap - kh * a.KW;
+        const int ci0 = cc * 32 + 4 * col4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int iy = iyb[i] + kh * a.dil, ix = ixb[i] + kw * a.dil;
+            const bool ok = mv[i] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                if (!a.up2) {
+                    v = *reinterpret_cast<const float4 *>(a.x + ((nb[i] + (long)iy * Ws + ix) * a.Cin + ci0));
+                } else {
+                    // tf.image.resize_bilinear(src, 2x), legacy mapping src = dst * 0.5 (ICNET_SPEC "bilinear resize")
+                    const int y0 = iy >> 1, x0 = ix >> 1;
+                    const int y1 = min(y0 + 1, Hs - 1), x1 = min(x0 + 1, Ws - 1);
+                    const float ly = (iy & 1) ? 0.5f : 0.0f, lx = (ix & 1) ? 0.5f : 0.0f;
+                    const float *b = a.x + nb[i] * a.Cin + ci0;
+                    const float4 tl = *reinterpret_cast<const float4 *>(b + ((long)y0 * Ws + x0) * a.Cin);
+                    const float4 tr = *reinterpret_cast<const float4 *>(b + ((long)y0 * Ws + x1) * a.Cin);
+                    const float4 bl = *reinterpret_cast<const float4 *>(b + ((long)y1 * Ws + x0) * a.Cin);
+                    const float4 br = *reinterpret_cast<const float4 *>(b + ((long)y1 * Ws + x1) * a.Cin);
+                    auto lerp2 = [&](float ctl, float ctr, float cbl, float cbr) {
+                        const float top = ctl + (ctr - ctl) * lx;
+                        const float bot = cbl + (cbr - cbl) * lx;
+                        return top + (bot - top) * ly;
+                    };
+                    v = make_float4(lerp2(tl.x, tr.x, bl.x, br.x), lerp2(tl.y, tr.y, bl.y, br.y),
+                                    lerp2(tl.z, tr.z, bl.z, br.z), lerp2(tl.w, tr.w, bl.w, br.w));
+                }
+            }
+            ra[i] = v;
+        }
+        const float *wb = a.wt + ((long)t * a.CoutP + n0) * 32;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) rb[j] = *reinterpret_cast<const float4 *>(wb + (long)(tid + 256 * j) * 4);
+    };
+    auto lds_write = [&](int buf) {
+        float *As = smem + buf * (BM + BN) * LDK;
+        float *Bs = As + BM * LDK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4 *>(As + ((tid >> 3) + 32 * i) * LDK + 4 * col4) = ra[i];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int idx = tid + 256 * j;
+            *reinterpret_cast<float4 *>(Bs + (idx >> 3) * LDK + 4 * (idx & 7)) = rb[j];
+        }
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nt][i] = 0.0f;
+
+    gload(0);
+    lds_write(0);
+    __syncthreads();
+    for (int t = 0; t < nchunks; ++t) {
+        const bool more = t + 1 < nchunks;
+        if (more) gload(t + 1);
+        const float *As = smem + (t & 1) * (BM + BN) * LDK;
+        const float *Bs = As + BM * LDK;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 af = *reinterpret_cast<const float4 *>(As + (32 * wave + r) * LDK + 8 * g + 4 * h);
+            swap32(af.x, af.y);  // af.x = (k0 | k1), af.y = (k4 | k5)
+            swap32(af.z, af.w);  // af.z = (k2 | k3), af.w = (k6 | k7)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float4 bf = *reinterpret_cast<const float4 *>(Bs + (32 * nt + r) * LDK + 8 * g + 4 * h);
+                swap32(bf.x, bf.y);
+                swap32(bf.z, bf.w);
+                acc[nt] = mfma32(af.x, bf.x, acc[nt]);
+                acc[nt] = mfma32(af.z, bf.z, acc[nt]);
+                acc[nt] = mfma32(af.y, bf.y, acc[nt]);
+                acc[nt] = mfma32(af.w, bf.w, acc[nt]);
+            }
+        }
+        if (more) lds_write((t + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: folded batch-norm, shortcut add, ReLU, store (128-B rows per lane half) --------
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = n0 + 32 * nt + r;
+        const float sc = a.scale[co], sh = a.shift[co];
+        const bool cok = co < a.Cout;
+        float rv[16];
+        if (a.res) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const long m = m0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
+                rv[i] = (cok && m < a.M) ? a.res[m * a.Cout + co] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const long m = m0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
+            float v = fmaf(acc[nt][i], sc, sh);
+            if (a.res) v = v + rv[i];
+            if (a.relu) v = v > 0.0f ? v : 0.0f;
+            if (cok && m < a.M) a.y[m * a.Cout + co] = v;
+        }
+    }
+}
+
+size_t igemm_relayout_floats(int KH, int KW, int Cin, int Cout)
+{
+    const int CoutP = (Cout + 31) / 32 * 32;
+    return (size_t)KH * KW * Cin * CoutP;
+}
+
+void igemm_relayout(const float *w, int KH, int KW, int Cin, int Cout, float *out)
+{
+    const int CoutP = (Cout + 31) / 32 * 32, cpt = Cin / 32;
+    memset(out, 0, sizeof(float) * igemm_relayout_floats(KH, KW, Cin, Cout));
+    for (int tap = 0; tap < KH * KW; ++tap)
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int co = 0; co < Cout; ++co)
+                out[(((size_t)tap * cpt + ci / 32) * CoutP + co) * 32 + ci % 32] = w[((size_t)tap * Cin + ci) * Cout + co];
+}
+
+bool igemm_supported(int Cin, int Cout, int KH, int KW)
+{
+    return Cin > 0 && Cin % 32 == 0 && Cout > 0 && KH >= 1 && KW >= 1 && KH <= 7 && KW <= 7;
+}
+
+hipError_t launch_igemm(const float *x, int N, int H, int W, int Cin, const float *wt, int KH, int KW, int Cout,
+                        int stride, int dil, const float *scale, const float *shift, const float *res, bool relu,
+                        bool up2, float *y, hipStream_t s)
+{
+    if (!igemm_supported(Cin, Cout, KH, KW) || stride < 1 || dil < 1) return hipErrorInvalidValue;
+    IgemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.wt = wt; a.y = y; a.scale = scale; a.shift = shift; a.res = res;
+    a.N = N; a.Cin = Cin; a.Cout = Cout; a.CoutP = (Cout + 31) / 32 * 32;
+    a.H = up2 ? 2 * H : H;  // H, W: dims of the tensor the conv SEES
+    a.W = up2 ? 2 * W : W;
+    a.KH = KH; a.KW = KW; a.stride = stride; a.dil = dil;
+    a.relu = relu ? 1 : 0;
+    a.up2 = up2 ? 1 : 0;
+    // TF "SAME": out = ceil(in/stride); pad_total = max((out-1)*stride + (k-1)*dil + 1 - in, 0); before = total/2
+    a.Ho = (a.H + stride - 1) / stride;
+    a.Wo = (a.W + stride - 1) / stride;
+    int th = (a.Ho - 1) * stride + (KH - 1) * dil + 1 - a.H; if (th < 0) th = 0;
+    int tw = (a.Wo - 1) * stride + (KW - 1) * dil + 1 - a.W; if (tw < 0) tw = 0;
+    a.pad_t = th / 2;
+    a.pad_l = tw / 2;
+    a.M = (long)N * a.Ho * a.Wo;
+    a.tiles_m = cdiv_i(a.M, IG_BM);
+    const int nb32 = a.CoutP / 32;
+    // widest column tile that divides the padded channel count and still leaves >= 2 workgroups per CU
+    int NT = nb32 % 4 == 0 ? 4 : (nb32 % 2 == 0 ? 2 : 1);
+    while (NT > 1 && (long)a.tiles_m * (nb32 / NT) < 512) NT >>= 1;
+    a.tiles_n = nb32 / NT;
+    a.ntiles = a.tiles_m * a.tiles_n;
+    a.xcd_chunk = (a.ntiles + 7) / 8;
+    const int grid = a.xcd_chunk * 8;
+    const double flops = 2.0 * (double)a.M * KH * KW * Cin * Cout;
+    const double bytes = 4.0 * ((double)N * H * W * Cin + (double)a.M * Cout * (res ? 2.0 : 1.0) +
+                                (double)KH * KW * Cin * Cout);
+    ProfScope prof(up2 ? "k_igemm_up2" : "k_igemm", flops, bytes, s);
+    if (NT == 4) hipLaunchKernelGGL(k_igemm<4>, dim3(grid), dim3(256), 0, s, a);
+    else if (NT == 2) hipLaunchKernelGGL(k_igemm<2>, dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_igemm<1>, dim3(grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// First convolution of a branch (ICNET_SPEC conv1_1_3x3_s2 on data_sub2, conv1_sub1 on the image):
+// 3x3 / stride 2 / SAME, CIN in {1,3,4} -> 32 channels, folded BN, ReLU.  One thread per output pixel, the 27 x 32
+// kernel taps are wave-uniform (scalar loads).  `sub` = 2 reads pixel (2y, 2x) of the image for conv-input pixel
+// (y, x): resize_bilinear(x, H/2, W/2) under the legacy mapping is exactly that pixel (lerp weights 0).
+// HBM-bound: reads the image once, writes 128 B per output pixel.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float to_unit_f(float v) { return v; }
+__device__ __forceinline__ float to_unit_f(uint8_t v) { return (float)v * (1.0f / 255.0f); }
+
+template <int CIN, typename TX>
+__global__ __launch_bounds__(256) void k_conv_first(const TX *__restrict__ x, const float *__restrict__ w,
+                                                    const float *__restrict__ scale, const float *__restrict__ shift,
+                                                    float *__restrict__ y, int N, int H, int W, int sub)
+{
+    constexpr int CO = 32;
+    const int Hc = H / sub, Wc = W / sub;          // dims of the conv input
+    const int Ho = (Hc + 1) / 2, Wo = (Wc + 1) / 2;
+    int th = (Ho - 1) * 2 + 3 - Hc; if (th < 0) th = 0;
+    int tw = (Wo - 1) * 2 + 3 - Wc; if (tw < 0) tw = 0;
+    const int pt = th / 2, pl = tw / 2;
+    const long total = (long)N * Ho * Wo;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < total; p += (long)gridDim.x * 256) {
+        const int ox = (int)(p % Wo);
+        const int oy = (int)((p / Wo) % Ho);
+        const long n = p / ((long)Wo * Ho);
+        float acc[CO];
+#pragma unroll
+        for (int c = 0; c < CO; ++c) acc[c] = 0.0f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int iy = 2 * oy - pt + kh;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ix = 2 * ox - pl + kw;
+                const bool ok = iy >= 0 && iy < Hc && ix >= 0 && ix < Wc;
+                const TX *xp = x + ((n * H + (long)iy * sub) * W + (long)ix * sub) * CIN;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) {
+                    const float xv = ok ? to_unit_f(xp[ci]) : 0.0f;
+                    const float *wr = w + ((kh * 3 + kw) * CIN + ci) * CO;
+#pragma unroll
+                    for (int co = 0; co < CO; ++co) acc[co] = fmaf(xv, wr[co], acc[co]);
+                }
+            }
+        }
+        float4 *yp = reinterpret_cast<float4 *>(y + p * CO);
+#pragma unroll
+        for (int q = 0; q < CO / 4; ++q) {
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float v = fmaf(acc[4 * q + k], scale[4 * q + k], shift[4 * q + k]);
+                o[k] = v > 0.0f ? v : 0.0f;
+            }
+            yp[q] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+hipError_t launch_conv_first(const void *x, bool x_is_u8, int N, int H, int W, int Cin, int sub, const float *w,
+                             const float *scale, const float *shift, float *y, hipStream_t s)
+{
+    if (sub != 1 && sub != 2) return hipErrorInvalidValue;
+    const int Hc = H / sub, Wc = W / sub;
+    const long total = (long)N * ((Hc + 1) / 2) * ((Wc + 1) / 2);
+    int grid = cdiv_i(total, 256);
+    if (grid > 1 << 20) grid = 1 << 20;
+    ProfScope prof("k_conv_first", 2.0 * (double)total * 9 * Cin * 32,
+                   (double)N * H * W * Cin * (x_is_u8 ? 1.0 : 4.0) / (sub * sub) + 4.0 * (double)total * 32, s);
+#define SSAL_CF(C)                                                                                                   \
+    case C:                                                                                                          \
+        if (x_is_u8)                                                                                                 \
+            hipLaunchKernelGGL((k_conv_first<C, uint8_t>), dim3(grid), dim3(256), 0, s, (const uint8_t *)x, w, scale, \
+                               shift, y, N, H, W, sub);                                                              \
+        else                                                                                                         \
+            hipLaunchKernelGGL((k_conv_first<C, float>), dim3(grid), dim3(256), 0, s, (const float *)x, w, scale,     \
+                               shift, y, N, H, W, sub);                                                              \
+        break;
+    switch (Cin) {
+        SSAL_CF(1) SSAL_CF(3) SSAL_CF(4)
+    default:
+        return hipErrorInvalidValue;
+    }
+#undef SSAL_CF
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// tf.nn.max_pool(ksize 3x3, strides 2, "SAME") (ICNET_SPEC pool1_3x3_s2); one float4 of channels per thread
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_maxpool3x3_s2(const float4 *__restrict__ x, int N, int H, int W, int C4,
+                                                       int Ho, int Wo, int pt, int pl, float4 *__restrict__ y)
+{
+    const long total = (long)N * Ho * Wo * C4;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
+        const int c = (int)(o % C4);
+        const long pix = o / C4;
+        const int ox = (int)(pix % Wo);
+        const int oy = (int)((pix / Wo) % Ho);
+        const long n = pix / ((long)Wo * Ho);
+        float4 best = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = 2 * oy - pt + dy;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = 2 * ox - pl + dx;
+                if (ix < 0 || ix >= W) continue;
+                const float4 v = x[((n * H + iy) * W + ix) * C4 + c];
+                if (v.x > best.x) best.x = v.x;
+                if (v.y > best.y) best.y = v.y;
+                if (v.z > best.z) best.z = v.z;
+                if (v.w > best.w) best.w = v.w;
+            }
+        }
+        y[o] = best;
+    }
+}
+
+hipError_t launch_maxpool3x3_s2(const float *x, int N, int H, int W, int C, float *y, hipStream_t s)
+{
+    if (C % 4) return hipErrorInvalidValue;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    int th = (Ho - 1) * 2 + 3 - H; if (th < 0) th = 0;
+    int tw = (Wo - 1) * 2 + 3 - W; if (tw < 0) tw = 0;
+    const long total = (long)N * Ho * Wo * (C / 4);
+    int grid = cdiv_i(total, 256);
+    if (grid > 1 << 20) grid = 1 << 20;
+    ProfScope prof("k_maxpool3x3_s2", 0.0, 4.0 * ((double)N * H * W * C + (double)N * Ho * Wo * C), s);
+    hipLaunchKernelGGL(k_maxpool3x3_s2, dim3(grid), dim3(256), 0, s, (const float4 *)x, N, H, W, C / 4, Ho, Wo,
+                       th / 2, tw / 2, (float4 *)y);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pyramid pooling (ICNET_SPEC conv5_3_pool{1,2,3,6}, conv5_3_sum).  Bins: b = 1 -> slot 0, b = 2 -> 1..4,
+// b = 3 -> 5..13, b = 6 -> 14..49.  k_ppm_pool: one thread per (image, bin, channel), fp32 sum in row-major order
+// divided by the count (the oracle's order).  k_ppm_sum: y = ((((x + up1) + up2) + up3) + up6), each up_b the
+// legacy-mapped bilinear resize of the b x b bin grid back to H x W.
+// ------------------------------------------------------------------------------------------------
+__device__ __host__ constexpr int ppm_bins(int k) { return k == 0 ? 1 : k == 1 ? 2 : k == 2 ? 3 : 6; }
+__device__ __host__ constexpr int ppm_base(int k) { return k == 0 ? 0 : k == 1 ? 1 : k == 2 ? 5 : 14; }
+constexpr int PPM_SLOTS = 50;
+
+__global__ __launch_bounds__(256) void k_ppm_pool(const float *__restrict__ x, int N, int H, int W, int C,
+                                                  float *__restrict__ pooled)
+{
+    const long total = (long)N * PPM_SLOTS * C;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
+        const int c = (int)(o % C);
+        const int slot = (int)((o / C) % PPM_SLOTS);
+        const long n = o / ((long)C * PPM_SLOTS);
+        const int k = slot >= 14 ? 3 : slot >= 5 ? 2 : slot >= 1 ? 1 : 0;
+        const int b = ppm_bins(k), idx = slot - ppm_base(k);
+        const int i = idx / b, j = idx % b;
+        const int y0 = (i * H) / b, y1 = ((i + 1) * H + b - 1) / b;
+        const int x0 = (j * W) / b, x1 = ((j + 1) * W + b - 1) / b;
+        float sum = 0.0f;
+        for (int yy = y0; yy < y1; ++yy)
+            for (int xx = x0; xx < x1; ++xx) sum += x[((n * H + yy) * W + xx) * C + c];
+        pooled[o] = sum / (float)((y1 - y0) * (x1 - x0));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ppm_sum(const float4 *__restrict__ x, const float4 *__restrict__ pooled,
+                                                 int N, int H, int W, int C4, float4 *__restrict__ y)
+{
+    const long total = (long)N * H * W * C4;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
+        const int c = (int)(o % C4);
+        const long pix = o / C4;
+        const int ox = (int)(pix % W);
+        const int oy = (int)((pix / W) % H);
+        const long n = pix / ((long)W * H);
+        float4 v = x[o];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int b = ppm_bins(k);
+            const float hs = (float)b / (float)H, ws = (float)b / (float)W;
+            const float fy = (float)oy * hs, fx = (float)ox * ws;
+            const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+            const int y1 = min(y0 + 1, b - 1), x1 = min(x0 + 1, b - 1);
+            const float ly = fy - (float)y0, lx = fx - (float)x0;
+            const float4 *pb = pooled + (n * PPM_SLOTS + ppm_base(k)) * C4 + c;
+            const float4 tl = pb[(y0 * b + x0) * C4], tr = pb[(y0 * b + x1) * C4];
+            const float4 bl = pb[(y1 * b + x0) * C4], br = pb[(y1 * b + x1) * C4];
+            auto lerp2 = [&](float ctl, float ctr, float cbl, float cbr) {
+                const float top = ctl + (ctr - ctl) * lx;
+                const float bot = cbl + (cbr - cbl) * lx;
+                return top + (bot - top) * ly;
+            };
+            v.x = v.x + lerp2(tl.x, tr.x, bl.x, br.x);
+            v.y = v.y + lerp2(tl.y, tr.y, bl.y, br.y);
+            v.z = v.z + lerp2(tl.z, tr.z, bl.z, br.z);
+            v.w = v.w + lerp2(tl.w, tr.w, bl.w, br.w);
+        }
+        y[o] = v;
+    }
+}
+
+hipError_t launch_ppm(const float *x, int N, int H, int W, int C, float *pooled, float *y, hipStream_t s)
+{
+    if (C % 4) return hipErrorInvalidValue;
+    {
+        const long total = (long)N * PPM_SLOTS * C;
+        ProfScope prof("k_ppm_pool", 0.0, 4.0 * 4.0 * (double)N * H * W * C, s);
+        hipLaunchKernelGGL(k_ppm_pool, dim3(cdiv_i(total, 256)), dim3(256), 0, s, x, N, H, W, C, pooled);
+    }
+    const long total = (long)N * H * W * (C / 4);
+    int grid = cdiv_i(total, 256);
+    if (grid > 1 << 20) grid = 1 << 20;
+    ProfScope prof("k_ppm_sum", 0.0, 8.0 * (double)N * H * W * C, s);
+    hipLaunchKernelGGL(k_ppm_sum, dim3(grid), dim3(256), 0, s, (const float4 *)x, (const float4 *)pooled, N, H, W,
+                       C / 4, (float4 *)y);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv6_interp + acquisition score.  lq = logits at 1/4 resolution [N,H,W,K]; the full-resolution logits are
+// resize_bilinear(lq, 4H, 4W) (legacy mapping src = dst * 0.25: y0 = oy >> 2, ly = (oy & 3) / 4).  One thread per
+// 1/4-resolution pixel = one 4x4 block of output pixels: it loads its four corner logit vectors once, forms
+// top/bottom rows per dx, the 16 interpolated logit vectors, and scores each in registers.  Outputs (optional):
+// label / mask uint8, confidence fp32 at [N,4H,4W]; always: one fp64 partial sum per block.
+// grid = (ceil(H*W/256), N): a block never straddles two images.
+// ------------------------------------------------------------------------------------------------
+template <int K, bool OUT>
+__global__ __launch_bounds__(256) void k_upscore(const float *__restrict__ lq, int H, int W, int measure,
+                                                 float threshold, double *__restrict__ partial,
+                                                 uint8_t *__restrict__ label, uint8_t *__restrict__ mask,
+                                                 float *__restrict__ conf)
+{
+    __shared__ double red[4];
+    const int n = blockIdx.y;
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    const float inv_logK = 1.0f / logf((float)K);
+    double local = 0.0;
+    if (q < (long)H * W) {
+        const int qx = (int)(q % W), qy = (int)(q / W);
+        const int qx1 = min(qx + 1, W - 1), qy1 = min(qy + 1, H - 1);
+        const float *img = lq + (long)n * H * W * K;
+        float tl[K], tr[K], bl[K], br[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            tl[k] = img[((long)qy * W + qx) * K + k];
+            tr[k] = img[((long)qy * W + qx1) * K + k];
+            bl[k] = img[((long)qy1 * W + qx) * K + k];
+            br[k] = img[((long)qy1 * W + qx1) * K + k];
+        }
+        const int OW = 4 * W;
+        const long obase = (long)n * 16 * H * W + (long)(4 * qy) * OW + 4 * qx;
+        unsigned lab4[4] = {0u, 0u, 0u, 0u}, msk4[4] = {0u, 0u, 0u, 0u};
+        float cf4[4][4];
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {
+            const float lx = 0.25f * (float)dx;
+            float top[K], bot[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                top[k] = tl[k] + (tr[k] - tl[k]) * lx;
+                bot[k] = bl[k] + (br[k] - bl[k]) * lx;
+            }
+#pragma unroll
+            for (int dy = 0; dy < 4; ++dy) {
+                const float ly = 0.25f * (float)dy;
+                float l[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) l[k] = top[k] + (bot[k] - top[k]) * ly;
+                int lab;
+                const float cf = pixel_score<K>(l, measure, inv_logK, lab);
+                local += (double)cf;
+                if (OUT) {
+                    lab4[dy] |= (unsigned)lab << (8 * dx);
+                    msk4[dy] |= (cf < threshold ? 0u : 1u) << (8 * dx);
+                    cf4[dy][dx] = cf;
+                }
+            }
+        }
+        if (OUT) {
+#pragma unroll
+            for (int dy = 0; dy < 4; ++dy) {
+                const long o = obase + (long)dy * OW;
+                if (label) *reinterpret_cast<unsigned *>(label + o) = lab4[dy];
+                if (mask) *reinterpret_cast<unsigned *>(mask + o) = msk4[dy];
+                if (conf) *reinterpret_cast<float4 *>(conf + o) = make_float4(cf4[dy][0], cf4[dy][1], cf4[dy][2], cf4[dy][3]);
+            }
+        }
+    }
+    const double rsum = block_sum_256(local, red);
+    if (threadIdx.x == 0) partial[(long)n * gridDim.x + blockIdx.x] = rsum;
+}
+
+int upscore_blocks(int H, int W) { return cdiv_i((long)H * W, 256); }
+
+hipError_t launch_upscore(const float *lq, int N, int H, int W, int K, int measure, float threshold, double *partial,
+                          uint8_t *label, uint8_t *mask, float *conf, hipStream_t s)
+{
+    dim3 grid(upscore_blocks(H, W), N), block(256);
+    ProfScope prof("k_upscore", 16.0 * (double)N * H * W * K * 6.0,
+                   4.0 * (double)N * H * W * K +
+                       16.0 * (double)N * H * W * ((label ? 1 : 0) + (mask ? 1 : 0) + (conf ? 4 : 0)), s);
+    const bool out = label || mask || conf;
+#define SSAL_US(KK)                                                                                              \
+    case KK:                                                                                                     \
+        if (out)                                                                                                 \
+            hipLaunchKernelGGL((k_upscore<KK, true>), grid, block, 0, s, lq, H, W, measure, threshold, partial,  \
+                               label, mask, conf);                                                               \
+        else                                                                                                     \
+            hipLaunchKernelGGL((k_upscore<KK, false>), grid, block, 0, s, lq, H, W, measure, threshold, partial, \
+                               label, mask, conf);                                                               \
+        break;
+    switch (K) {
+        SSAL_US(2) SSAL_US(3) SSAL_US(4) SSAL_US(5) SSAL_US(6) SSAL_US(7) SSAL_US(8) SSAL_US(9) SSAL_US(10)
+        SSAL_US(11) SSAL_US(12) SSAL_US(13) SSAL_US(14) SSAL_US(15) SSAL_US(16) SSAL_US(17) SSAL_US(18)
+        SSAL_US(19) SSAL_US(20) SSAL_US(21) SSAL_US(22) SSAL_US(23) SSAL_US(24) SSAL_US(25) SSAL_US(26)
+        SSAL_US(27) SSAL_US(28) SSAL_US(29) SSAL_US(30) SSAL_US(31) SSAL_US(32)
+    default:
+        return hipErrorInvalidValue;
+    }
+#undef SSAL_US
+    return hipGetLastError();
+}
+
+}  // namespace ssal

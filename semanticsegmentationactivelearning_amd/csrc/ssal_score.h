@@ -1,0 +1,70 @@
+// ssal_score.h -- per-pixel acquisition score + block reductions shared by the score kernels
+// (k_final_score / k_score_logits in ssal_kernels.hip, k_upscore in ssal_icnet_kernels.hip).  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ssal {
+
+// ------------------------------------------------------------------------------------------------
+// Per-pixel acquisition score (active_learning.py:239-260) on K logits held in registers.
+//   softmax: p_k = exp(x_k - m) / S,  S = sum_k exp(x_k - m)
+//   entropy   : conf = 1 - H/log(K),  H = -sum p log p = log S - sum_k e_k (x_k - m) / S
+//               (the reference adds FLT_MIN inside the log; it changes H by < 1e-36)
+//   margin    : conf = p_(1) - p_(2) = (1 - e_(2)) / S
+//   confidence: conf = p_(1) = 1 / S
+// label = first maximum of the logits (tf.math.argmax, :234-236).
+// Non-finite logits (policy, tests/test_gpu_parity.py::test_score_nonfinite_policy):
+//   * exp underflow (x_k - m < -104) and x_k = -inf give p_k = 0 exactly and contribute 0 to H -- the value the
+//     reference's  -p * log(p + FLT_MIN)  takes at p = 0;
+//   * a NaN logit, or a +inf maximum (inf - inf in the softmax), makes the pixel's confidence NaN, as the
+//     reference's tf.nn.softmax does; the per-image mean is then NaN and np.argpartition ranks it last.
+// ------------------------------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ float pixel_score(const float (&l)[K], int measure, float inv_logK,
+                                             int &label)
+{
+    float m = l[0];
+    int am = 0;
+#pragma unroll
+    for (int k = 1; k < K; ++k)
+        if (l[k] > m) { m = l[k]; am = k; }
+    label = am;
+    float S = 0.0f, T = 0.0f, e2 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float d = l[k] - m;
+        const float e = __expf(d);  // NaN (NaN logit, or inf - inf) propagates into S and from there into every measure
+        S += e;
+        // -inf logits (p = 0 exactly, like the reference's softmax): keep 0 * d finite so T stays a number
+        T = fmaf(e, fmaxf(d, -3.0e38f), T);
+        if (k != am && e > e2) e2 = e;
+    }
+    if (measure == 0) {
+        const float Hn = __logf(S) - T / S;
+        return 1.0f - Hn * inv_logK;
+    } else if (measure == 1) {
+        return (1.0f - e2) / S;
+    }
+    return 1.0f / S;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// block-wide fp64 sum, result valid in thread 0 (256 threads = 4 waves)
+__device__ __forceinline__ double block_sum_256(double v, double *lds4)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) lds4[wid] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) r = ((lds4[0] + lds4[1]) + lds4[2]) + lds4[3];
+    return r;
+}
+
+}  // namespace ssal

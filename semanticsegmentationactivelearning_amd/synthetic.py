@@ -123,3 +123,41 @@ def enet_params_dict(model):
         for attr, var in layer.abi_tensors().items():
             out["%s.%s" % (layer.name, attr)] = var.numpy()
     return out
+
+
+def randomize_icnet(model, seed=0, cls_gain=1.0):
+    """Seeded synthetic weights for a built ``models.ICNet`` (layer by layer, ``add_weight`` order): kernels
+    He-uniform (ReLU network; the ``*_1x1_increase`` convs at a third of that so the 16 residual bottlenecks do not
+    blow the activations up), batch-norm statistics randomised, classifier scaled by ``cls_gain`` so the softmax is
+    not near-uniform and per-image scores separate."""
+    rng = np.random.default_rng(seed)
+    for layer in model.layers:
+        for var in layer.creation_order_variables:
+            leaf = var.name.rsplit("/", 1)[-1]
+            shape = var.shape
+            if leaf == "Kernel":
+                lim = np.sqrt(6.0 / (shape[0] * shape[1] * shape[2]))
+                val = rng.uniform(-lim, lim, size=shape).astype(np.float32)
+                if layer.name.endswith("_1x1_increase"):
+                    val = val * np.float32(1.0 / 3.0)
+                if layer.name == "conv6_cls":
+                    val = val * np.float32(cls_gain)
+            elif leaf == "Bias":
+                val = rng.normal(0.0, 0.1, size=shape).astype(np.float32)
+            elif leaf == "Mean":
+                val = rng.normal(0.0, 0.1, size=shape).astype(np.float32)
+            elif leaf == "Variance":
+                val = rng.uniform(0.5, 1.5, size=shape).astype(np.float32)
+            elif leaf == "Gamma":
+                val = rng.uniform(0.8, 1.2, size=shape).astype(np.float32)
+            elif leaf == "Beta":
+                val = rng.normal(0.0, 0.1, size=shape).astype(np.float32)
+            else:
+                raise RuntimeError("unexpected variable %s" % var.name)
+            var.assign(val)
+    return model
+
+
+def icnet_params_dict(model):
+    """{"<layer>.<attr>": float32 ndarray} in the C-ABI naming (what the parity oracle consumes)"""
+    return enet_params_dict(model)

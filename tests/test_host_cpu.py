@@ -18,9 +18,12 @@ HEADER = os.path.join(ROOT, "include", "ssal_enet.h")
 
 
 def header_functions():
-    src = open(HEADER).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(ssal_[a-z0-9_]+)\s*\(", src)))
+    names = set()
+    for hdr in (HEADER, os.path.join(os.path.dirname(HEADER), "ssal_icnet.h")):
+        src = open(hdr).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(ssal_[a-z0-9_]+)\s*\(", src))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():

@@ -1,0 +1,254 @@
+"""GPU parity tests of the ICNet row (BASELINE config C4): the HIP path through the C ABI (include/ssal_icnet.h)
+against the CPU oracle (oracle/icnet_oracle.py) on identical seeded inputs.
+
+PARITY STATUS of this row: unpinned AND undefined -- the reference's models/icnet/icnet.py:1-7 is an empty class;
+ICNET_SPEC.md defines the network.  What is asserted: conv outputs, logits and labels bit-exact against the C
+restatement (same accumulation order), <= 1e-4 against the independent torch restatement, confidences <= 1e-4
+(north_star tolerance), per-image float64 means <= 1e-6, top-k id sets equal.
+"""
+import numpy as np
+import pytest
+import torch
+
+import semanticsegmentationactivelearning_amd as ssal
+from helpers import frames, report_diff
+from oracle import enet_oracle as orc
+from oracle import icnet_oracle as ico
+from oracle import torch_restatement as tr
+from semanticsegmentationactivelearning_amd import _lib, active_learning as al, synthetic as syn
+from semanticsegmentationactivelearning_amd.models.util import conv_ops as cops
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4  # north_star: softmax / margin within 1e-4 fp32
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    torch.cuda.set_device(0)
+    _lib.lib()
+    yield
+    torch.cuda.synchronize()
+
+
+@pytest.fixture(scope="module")
+def icnet19():
+    net = ssal.ICNet(19)
+    net.build((None, None, None, 3))
+    syn.randomize_icnet(net, seed=0)
+    return net, syn.icnet_params_dict(net)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _bn(rng, c):
+    return (rng.normal(0, 0.1, c).astype(np.float32), rng.uniform(0.5, 1.5, c).astype(np.float32),
+            rng.uniform(0.8, 1.2, c).astype(np.float32), rng.normal(0, 0.1, c).astype(np.float32))
+
+
+def _oracle_conv(x, k, stride, dil, bn, bias, res, relu, up2):
+    if up2:
+        x = ico.resize_bilinear(x, 2 * x.shape[1], 2 * x.shape[2])
+    y = orc.conv2d_same(x, k, stride=stride, dil=dil)
+    if bn is not None:
+        s, t = orc.bn_fold(*bn)
+        return ico.affine_add_relu(y, s, t, res, relu)
+    return ico.affine_add_relu(y, None, bias, res, relu)
+
+
+# ---- the fused convolution operator (every ICNet layer) ---------------------------------------------
+@pytest.mark.parametrize("kh,cin,cout,stride,dil,n,h,w,res,relu,up2", [
+    (1, 32, 32, 1, 1, 2, 9, 13, False, True, False),
+    (1, 64, 128, 1, 1, 1, 16, 20, True, True, False),
+    (1, 128, 64, 2, 1, 2, 10, 14, False, False, False),     # stride-2 1x1 (conv3_1 reduce / proj)
+    (3, 32, 32, 1, 1, 1, 12, 17, False, True, False),
+    (3, 32, 64, 1, 1, 2, 7, 9, False, True, False),
+    (3, 32, 32, 2, 1, 1, 16, 24, False, True, False),       # conv2_sub1
+    (3, 32, 32, 2, 1, 1, 15, 11, False, True, False),       # odd dims: SAME pads (1, 1)
+    (3, 64, 64, 1, 1, 1, 6, 8, False, True, False),
+    (3, 128, 128, 1, 2, 1, 12, 16, False, True, False),     # dilation 2 (conv4)
+    (3, 256, 256, 1, 4, 1, 9, 10, False, True, False),      # dilation 4 (conv5)
+    (1, 1024, 256, 1, 1, 1, 4, 8, False, True, False),
+    (1, 256, 1024, 1, 1, 1, 4, 6, True, True, False),
+    (3, 256, 128, 1, 2, 1, 5, 7, True, True, True),         # conv_sub4: 2x interp inside the conv + fusion add
+    (3, 128, 128, 1, 2, 2, 6, 9, True, True, True),         # conv_sub2
+    (1, 128, 19, 1, 1, 1, 7, 5, False, False, True),        # conv6_cls: 2x interp + bias, 19 of 32 columns
+    (1, 32, 5, 1, 1, 3, 3, 3, False, False, False),
+    (3, 32, 32, 1, 1, 1, 130, 3, False, True, False),       # more pixels than one 128-row tile, ragged tail
+])
+def test_conv_bn_act_bit_exact(kh, cin, cout, stride, dil, n, h, w, res, relu, up2):
+    rng = np.random.default_rng(kh * 1000 + cin + cout + h)
+    x = rng.normal(size=(n, h, w, cin)).astype(np.float32)
+    k = (rng.normal(size=(kh, kh, cin, cout)) / np.sqrt(kh * kh * cin)).astype(np.float32)
+    use_bias = cout in (19, 5)
+    bn = None if use_bias else _bn(rng, cout)
+    bias = rng.normal(size=cout).astype(np.float32) if use_bias else None
+    hh, ww = (2 * h, 2 * w) if up2 else (h, w)
+    oh, ow = -(-hh // stride), -(-ww // stride)
+    r = rng.normal(size=(n, oh, ow, cout)).astype(np.float32) if res else None
+    want = _oracle_conv(x, k, stride, dil, bn, bias, r, relu, up2)
+    got = cops.conv_bn_act(dev(x), k, stride, dil, bn=bn, bias=bias, residual=None if r is None else dev(r),
+                           relu=relu, upsample2x=up2)
+    report_diff("conv_bn_act", got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("cin,h,w", [(3, 16, 24), (3, 17, 9), (1, 8, 8), (4, 10, 12)])
+def test_first_conv_bit_exact(cin, h, w):
+    rng = np.random.default_rng(cin + h)
+    x = rng.uniform(0, 1, size=(2, h, w, cin)).astype(np.float32)
+    k = (rng.normal(size=(3, 3, cin, 32)) / 5).astype(np.float32)
+    bn = _bn(rng, 32)
+    want = _oracle_conv(x, k, 2, 1, bn, None, None, True, False)
+    got = cops.conv_bn_act(dev(x), k, 2, 1, bn=bn, relu=True)
+    report_diff("first conv", got.cpu().numpy(), want)
+
+
+def test_conv_argument_errors():
+    x = torch.zeros((1, 4, 4, 24), device="cuda")
+    with pytest.raises(ValueError):
+        cops.conv_bn_act(x, np.zeros((3, 3, 24, 32), np.float32))  # cin % 32 != 0 and not a first layer
+    with pytest.raises(ValueError):
+        cops.conv_bn_act(torch.zeros((1, 4, 4, 32), device="cuda"), np.zeros((3, 3, 64, 32), np.float32))
+
+
+@pytest.mark.parametrize("n,h,w,c", [(2, 16, 24, 64), (1, 9, 7, 8), (1, 2, 2, 4)])
+def test_max_pool_3x3_s2(n, h, w, c):
+    x = np.random.default_rng(h).normal(size=(n, h, w, c)).astype(np.float32)
+    report_diff("maxpool", cops.max_pool_3x3_s2(dev(x)).cpu().numpy(), ico.maxpool3x3_s2(x))
+
+
+@pytest.mark.parametrize("n,h,w,c", [(2, 32, 64, 64), (1, 7, 9, 8), (1, 2, 4, 1024), (1, 1, 1, 4)])
+def test_pyramid_pooling(n, h, w, c):
+    x = np.random.default_rng(w).normal(size=(n, h, w, c)).astype(np.float32)
+    report_diff("ppm", cops.pyramid_pooling(dev(x)).cpu().numpy(), ico.pyramid_pooling(x))
+
+
+@pytest.mark.parametrize("measure", ["margin", "entropy", "confidence"])
+@pytest.mark.parametrize("n,h,w,k", [(2, 8, 12, 19), (1, 5, 3, 6), (1, 16, 16, 2)])
+def test_upscore_kernel(measure, n, h, w, k):
+    """4x bilinear + score fused == resize_bilinear then score, bit-exact labels, conf within 1e-4"""
+    lq = (np.random.default_rng(k + h).normal(size=(n, h, w, k)) * 4).astype(np.float32)
+    full = ico.resize_bilinear(lq, 4 * h, 4 * w)
+    want_mean, want_conf, want_label = orc.score_logits(full, measure)
+    thr = float(np.median(want_conf))
+    s, e = cops.upscore_logits(dev(lq), measure, threshold=thr, return_label=True, return_mask=True,
+                               return_confidence=True)
+    report_diff("label", e["label"].cpu().numpy(), want_label)
+    conf = e["confidence"].cpu().numpy()
+    report_diff("confidence", conf, want_conf, exact=False, atol=TOL)
+    report_diff("mean", s.cpu().numpy(), want_mean, exact=False, atol=1e-6)
+    assert (e["mask"].cpu().numpy() == (conf >= np.float32(thr))).all()
+    # score-only launch (no per-pixel outputs) gives the same means
+    assert torch.equal(s, cops.upscore_logits(dev(lq), measure))
+
+
+# ---- whole network --------------------------------------------------------------------------------
+def _check_net(net, P, x, tag, every_endpoint=True):
+    ep = {}
+    want = ico.icnet_forward(P, x, ep)
+    got = net(dev(x), training=False).cpu().numpy()
+    if every_endpoint:
+        names = net.endpoint_names()
+        assert len(names) > 60
+        for nm in names:
+            report_diff("%s %s" % (tag, nm), net.endpoint(nm).cpu().numpy(), ep[nm])
+    report_diff(tag + " logits vs C oracle (bit-exact)", got, want)
+    return got, want
+
+
+def test_every_block_and_logits_bit_exact(icnet19):
+    """every materialised ICNET_SPEC layer output (69 tensors) + the logits, 2 frames of 64x128"""
+    net, P = icnet19
+    x = frames([0, 1], 64, 128, 3)
+    got, want = _check_net(net, P, x, "64x128")
+    wb = tr.icnet_forward(P, x)
+    report_diff("logits vs torch restatement", got, wb, exact=False, atol=TOL)
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 32, 32), (3, 96, 64), (1, 160, 224)])
+def test_forward_ragged_shapes(icnet19, n, h, w):
+    net, P = icnet19
+    _check_net(net, P, frames(list(range(20, 20 + n)), h, w, 3), "%dx%dx%d" % (n, h, w), every_endpoint=(h < 100))
+
+
+@pytest.mark.parametrize("measure", ["margin", "entropy", "confidence"])
+def test_score_matches_oracle(icnet19, measure):
+    net, P = icnet19
+    x = frames([3, 4, 5], 64, 96, 3)
+    want_mean, want_conf, want_label, _ = ico.score_images(P, x, measure)
+    s, e = net.score(dev(x), measure, return_label=True, return_confidence=True)
+    report_diff("label (bit-exact argmax)", e["label"].cpu().numpy(), want_label)
+    report_diff("confidence", e["confidence"].cpu().numpy(), want_conf, exact=False, atol=TOL)
+    report_diff("mean", s.cpu().numpy(), want_mean, exact=False, atol=1e-6)
+    # fused score == score of the materialised logits (same per-pixel bits; the float64 block sums differ in order)
+    s2, e2 = al.score_logits(net(dev(x), training=False), measure, return_confidence=True)
+    assert torch.equal(e["confidence"], e2["confidence"])
+    assert torch.allclose(s, s2, rtol=0, atol=1e-12)
+    # bitwise reproducible
+    assert torch.equal(s, net.score(dev(x), measure))
+
+
+def test_uint8_frames_and_other_class_counts():
+    net = ssal.ICNet(6)
+    net.build((None, None, None, 4))
+    syn.randomize_icnet(net, seed=3)
+    P = syn.icnet_params_dict(net)
+    xu = syn.synth_frames_device(7, 2, 64, 64, 4, dtype=torch.uint8)
+    xf = syn.synth_frames_device(7, 2, 64, 64, 4)
+    a, b = net(xu, training=False), net(xf, training=False)
+    assert torch.equal(a, b)
+    report_diff("4-channel / 6-class logits", b.cpu().numpy(), ico.icnet_forward(P, xf.cpu().numpy()))
+    assert torch.equal(net.score(xu, "margin"), net.score(xf, "margin"))
+
+
+def test_rank_confidence_margin_topk_ids_match_oracle(icnet19):
+    """config C4 end to end at a size the oracle finishes in seconds: ICNet + margin + top-k over a pool"""
+    net, P = icnet19
+    ids = list(range(40, 52))
+    h, w, bs, k = 64, 64, 4, 5
+    batches = [(syn.synth_frames_device(ids[i], bs, h, w, 3), np.arange(i, i + bs)) for i in range(0, len(ids), bs)]
+    unlabelled = np.array([0, 1, 2, 4, 5, 7, 8, 9, 10, 11])
+    low, uconf = al.rank_confidence(net, batches, len(ids), unlabelled, k, measure="margin")
+    want_mean = ico.score_images(P, frames(ids, h, w, 3), "margin")[0]
+    want_low, want_u = orc.rank_lowest(want_mean, unlabelled, k)
+    srt = np.sort(want_u)
+    assert srt[k] - srt[k - 1] > 1e-4, "fixture must separate the k-th boundary"
+    assert set(low.tolist()) == set(want_low.tolist())
+    report_diff("unlabelled confidence", uconf, want_u, exact=False, atol=1e-6)
+
+
+def test_weight_update_and_errors(icnet19):
+    net = ssal.ICNet(19)
+    net.build((None, None, None, 3))
+    syn.randomize_icnet(net, seed=9)
+    x = syn.synth_frames_device(0, 1, 32, 64, 3)
+    a = net(x, training=False).clone()
+    net.conv6_cls.bias.assign(net.conv6_cls.bias.numpy() + 1.0)
+    b = net(x, training=False)
+    assert torch.allclose(a + 1.0, b, atol=1e-5)
+    with pytest.raises(ValueError):
+        net(torch.zeros((1, 40, 64, 3), device="cuda"), training=False)
+    with pytest.raises(NotImplementedError):
+        net(x, training=True)
+    with pytest.raises(NotImplementedError):
+        net.score(x, "bald")
+    with pytest.raises(ValueError):
+        net.endpoint("sub24_sum_interp")  # evaluated inside conv_sub2, never materialised
+
+
+def test_full_resolution_frame_bit_exact(icnet19):
+    """one 1024x2048 frame (config C4's size): 1/4-resolution class scores bit-exact, labels bit-exact, margin
+    mean within 1e-6 of the oracle"""
+    net, P = icnet19
+    x = frames([2], 1024, 2048, 3)
+    ep = {}
+    want_q = ico.icnet_forward(P, x, ep, full_logits=False)
+    s, e = net.score(dev(x), "margin", return_label=True)
+    report_diff("conv6_cls @1024x2048", net.endpoint("conv6_cls").cpu().numpy(), want_q)
+    report_diff("sub24_sum @1024x2048", net.endpoint("sub24_sum").cpu().numpy(), ep["sub24_sum"])
+    full = ico.resize_bilinear(want_q, 1024, 2048)
+    want_mean, _, want_label = orc.score_logits(full, "margin")
+    report_diff("label", e["label"].cpu().numpy(), want_label)
+    report_diff("margin mean", s.cpu().numpy(), want_mean, exact=False, atol=1e-6)

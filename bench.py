@@ -55,7 +55,10 @@ def parse():
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--classes", type=int, default=19)
     ap.add_argument("--channels", type=int, default=3)
-    ap.add_argument("--measure", default="entropy")
+    ap.add_argument("--model", choices=["enet", "icnet"], default="enet",
+                    help="enet: BASELINE configs[1] (the metric's workload); icnet: configs[3] (ICNet multi-scale, use "
+                         "--measure margin), architecture pinned in ICNET_SPEC.md")
+    ap.add_argument("--measure", default=None, help="entropy | margin | confidence (default: entropy, margin for icnet)")
     ap.add_argument("--input-dtype", choices=["f32", "u8"], default="f32",
                     help="resident frames: float32 in [0,1] (the reference's model input) or the decoded uint8 "
                          "frames, converted inside the Initial kernel (same bits out)")
@@ -74,7 +77,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(P, h, w, c, measure, budget_s, c1=None):
+def cpu_baseline(P, h, w, c, measure, budget_s, c1=None, model="enet"):
     """torch-CPU restatement of the reference path (oracle/torch_restatement.py) on a bounded
     sample: single 1024x2048 frames, 1 warm-up + as many repeats as fit the budget (>= 2)."""
     import torch
@@ -85,14 +88,15 @@ def cpu_baseline(P, h, w, c, measure, budget_s, c1=None):
     torch.set_num_threads(cores)
     log("cpu baseline: %d threads (affinity %d, cpu_count %s)" % (cores, len(os.sched_getaffinity(0)), os.cpu_count()))
     x = syn.synth_frames_f32([0], h, w, c)
+    score_images = tr.icnet_score_images if model == "icnet" else tr.score_images
     t0 = time.perf_counter()
-    tr.score_images(P, x, measure)  # warm-up
+    score_images(P, x, measure)  # warm-up
     log("cpu baseline warm-up %.2f s" % (time.perf_counter() - t0))
     times = []
     t_all = time.perf_counter()
     while len(times) < 2 or (time.perf_counter() - t_all) < budget_s:
         t0 = time.perf_counter()
-        tr.score_images(P, x, measure)
+        score_images(P, x, measure)
         times.append(time.perf_counter() - t0)
         log("cpu baseline run %d: %.2f s" % (len(times), times[-1]))
         if len(times) >= 20:
@@ -158,9 +162,17 @@ def main():
         raise SystemExit("refusing to time a library whose switches are not at their shipping values: %s" % knobs)
 
     h, w, c, bs = args.height, args.width, args.channels, args.batch
-    net = ssal.ENet(args.classes)
-    net.build((None, None, None, c))
-    syn.randomize_enet(net, seed=0)
+    if args.measure is None:
+        args.measure = "margin" if args.model == "icnet" else "entropy"
+    if args.model == "icnet":
+        net = ssal.ICNet(args.classes)
+        net.build((None, None, None, c))
+        syn.randomize_icnet(net, seed=0)
+    else:
+        net = ssal.ENet(args.classes)
+        net.build((None, None, None, c))
+        syn.randomize_enet(net, seed=0)
+    model_name = "ICNet" if args.model == "icnet" else "ENet"
 
     # ---- this rank's shard of the pool, device-resident before the clock starts -------------------
     positions = al.shard_positions(POOL, rank, world)
@@ -240,13 +252,15 @@ def main():
     if rank == 0:
         value = total_frames / elapsed
         result = {
-            "metric": "unlabelled-pool images/sec scored (ENet, 1024x2048)",
+            "metric": "unlabelled-pool images/sec scored (%s, %dx%d)" % (model_name, h, w),
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: ENet pool of %d synthetic %dx%dx%d frames, %s acquisition, "
-                                   "batch %d, K=%d, top-%d select%s" % (POOL, h, w, c, args.measure, bs, args.classes, TOP_K,
+            "config": {"workload": "%s pool of %d synthetic %dx%dx%d frames, %s acquisition, "
+                                   "batch %d, K=%d, top-%d select%s" % ("configs[3]: ICNet multi-scale (1/4, 1/2, 1; ICNET_SPEC.md)"
+                                                                        if args.model == "icnet" else "configs[1]: ENet",
+                                                                        POOL, h, w, c, args.measure, bs, args.classes, TOP_K,
                                                                         ", uint8 resident frames" if args.input_dtype == "u8" else ""),
                        "frames_scored": int(total_frames), "resident_batches_per_rank": n_resident,
                        "sharding": "strided pool shard per rank, one all-gather of (index, score)"},
@@ -278,7 +292,7 @@ def main():
         # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); null if not collected
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc", "traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc", "traffic_%s.json" % args.model)))
             traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch")
         except Exception:
             pass
@@ -297,11 +311,13 @@ def main():
     # ---- CPU baseline leg (rank 0, N=1 only) ------------------------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         P = syn.enet_params_dict(net)
-        net1 = ssal.ENet(19)
-        net1.build((None, None, None, 3))
-        syn.randomize_enet(net1, seed=0)
-        result["cpu_baseline"] = cpu_baseline(P, h, w, c, args.measure, args.cpu_seconds,
-                                              c1=(syn.enet_params_dict(net1), 19))
+        c1 = None
+        if args.model == "enet":
+            net1 = ssal.ENet(19)
+            net1.build((None, None, None, 3))
+            syn.randomize_enet(net1, seed=0)
+            c1 = (syn.enet_params_dict(net1), 19)
+        result["cpu_baseline"] = cpu_baseline(P, h, w, c, args.measure, args.cpu_seconds, c1=c1, model=args.model)
         result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
 
     if rank == 0:

@@ -188,7 +188,9 @@ int check_dims(const ssal_icnet *net, int n, int h, int w)
     if (!net->committed) return fail(SSAL_ESTATE, "ssal_icnet_commit() has not been called");
     if (n <= 0 || h <= 0 || w <= 0) return fail(SSAL_EINVAL, "bad dims n=%d h=%d w=%d", n, h, w);
     if (h % 32 || w % 32) return fail(SSAL_EINVAL, "ICNet needs H and W divisible by 32 (got %dx%d)", h, w);
-    if ((int64_t)n * h * w > ((int64_t)1 << 31)) return fail(SSAL_EINVAL, "batch too large (n=%d h=%d w=%d): split it", n, h, w);
+    // the convolution kernels address each tensor with 32-bit byte offsets; the largest one (conv1_sub1's output) holds
+    // n*h*w/4 pixels x 32 floats = 32 bytes per input pixel
+    if ((int64_t)n * h * w >= ((int64_t)1 << 27)) return fail(SSAL_EINVAL, "batch too large (n=%d h=%d w=%d): split it", n, h, w);
     return SSAL_OK;
 }
 

@@ -36,8 +36,13 @@ static inline int cdiv_i(long a, long b) { return (int)((a + b - 1) / b); }
 // ascending k order (ssal_mfma.h), so no LDS transpose is needed.
 // ------------------------------------------------------------------------------------------------
 constexpr int IG_BM = 128, IG_LDK = 36;
+constexpr unsigned IG_OOB = 0xFFFFFFFFu;  // a byte offset no tensor reaches: raw buffer loads return 0, stores are dropped
 
-template <int NT>
+// Addressing: every tensor is reached through a raw buffer resource (base in SGPRs, range = tensor bytes) plus a
+// 32-bit per-lane byte offset.  A pixel row's offset is computed ONCE; per K-chunk it only receives a wave-uniform
+// increment (tap displacement + channel chunk), and taps that fall into the SAME zero padding (or rows past the end of
+// the tensor) use the out-of-range offset, which the hardware answers with zeros -- no branches, no 64-bit math.
+template <int NT, bool UP2>
 __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
 {
     constexpr int BM = IG_BM, BN = 32 * NT, LDK = IG_LDK;
@@ -51,68 +56,71 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
         if (tile >= a.ntiles) return;  // whole workgroup, before any barrier
     }
     const int tn = tile % a.tiles_n, tm = tile / a.tiles_n;
-    const long m0 = (long)tm * BM;
+    const int m0 = tm * BM;  // M < 2^31 (launcher): 32-bit pixel indices keep the row decode to 32-bit divisions
     const int n0 = tn * BN;
+    const int M = (int)a.M;
+
+    const int Hs = UP2 ? a.H >> 1 : a.H, Ws = UP2 ? a.W >> 1 : a.W;  // dims of the tensor in memory
+    const rsrc_t xrs = make_rsrc(a.x, (unsigned)((long)a.N * Hs * Ws * a.Cin * 4));
+    const rsrc_t wrs = make_rsrc(a.wt, (unsigned)((long)a.KH * a.KW * a.Cin * a.CoutP * 4));
 
     // ---- per-thread A rows: (tid >> 3) + 32 i, channel quad tid & 7 ------------------------------
     const int col4 = tid & 7;
     int iyb[4], ixb[4];
-    long nb[4];
+    unsigned nbase[4];  // byte offset of the row's image
     bool mv[4];
-    const int Hs = a.up2 ? a.H >> 1 : a.H, Ws = a.up2 ? a.W >> 1 : a.W;  // dims of the tensor in memory
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const long m = m0 + (tid >> 3) + 32 * i;
-        mv[i] = m < a.M;
-        const long mm = mv[i] ? m : 0;
-        const int ox = (int)(mm % a.Wo);
-        const long t = mm / a.Wo;
-        const int oy = (int)(t % a.Ho);
-        const long n = t / a.Ho;
+        const int m = m0 + (tid >> 3) + 32 * i;
+        mv[i] = m < M;
+        const unsigned mm = mv[i] ? (unsigned)m : 0u;
+        const unsigned t = mm / (unsigned)a.Wo;
+        const int ox = (int)(mm - t * (unsigned)a.Wo);
+        const unsigned n = t / (unsigned)a.Ho;
+        const int oy = (int)(t - n * (unsigned)a.Ho);
         iyb[i] = oy * a.stride - a.pad_t;
         ixb[i] = ox * a.stride - a.pad_l;
-        nb[i] = n * (long)Hs * Ws;
+        nbase[i] = (unsigned)n * (unsigned)(Hs * Ws * a.Cin * 4) + 16u * col4;
     }
     const int cpt = a.Cin >> 5;             // chunks per tap
     const int nchunks = a.KH * a.KW * cpt;
+    const unsigned rowb = (unsigned)(Ws * a.Cin * 4), pixb = (unsigned)(a.Cin * 4);
 
     float4 ra[4], rb[NT];
     auto gload = [&](int t) {
         const int tap = t / cpt, cc = t - tap * cpt;
         const int kh = tap / a.KW, kw = tap - kh * a.KW;
-        const int ci0 = cc * 32 + 4 * col4;
+        const unsigned cofs = 128u * cc;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int iy = iyb[i] + kh * a.dil, ix = ixb[i] + kw * a.dil;
             const bool ok = mv[i] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
-                if (!a.up2) {
-                    v = *reinterpret_cast<const float4 *>(a.x + ((nb[i] + (long)iy * Ws + ix) * a.Cin + ci0));
-                } else {
-                    // tf.image.resize_bilinear(src, 2x), legacy mapping src = dst * 0.5 (ICNET_SPEC "bilinear resize")
-                    const int y0 = iy >> 1, x0 = ix >> 1;
-                    const int y1 = min(y0 + 1, Hs - 1), x1 = min(x0 + 1, Ws - 1);
-                    const float ly = (iy & 1) ? 0.5f : 0.0f, lx = (ix & 1) ? 0.5f : 0.0f;
-                    const float *b = a.x + nb[i] * a.Cin + ci0;
-                    const float4 tl = *reinterpret_cast<const float4 *>(b + ((long)y0 * Ws + x0) * a.Cin);
-                    const float4 tr = *reinterpret_cast<const float4 *>(b + ((long)y0 * Ws + x1) * a.Cin);
-                    const float4 bl = *reinterpret_cast<const float4 *>(b + ((long)y1 * Ws + x0) * a.Cin);
-                    const float4 br = *reinterpret_cast<const float4 *>(b + ((long)y1 * Ws + x1) * a.Cin);
-                    auto lerp2 = [&](float ctl, float ctr, float cbl, float cbr) {
-                        const float top = ctl + (ctr - ctl) * lx;
-                        const float bot = cbl + (cbr - cbl) * lx;
-                        return top + (bot - top) * ly;
-                    };
-                    v = make_float4(lerp2(tl.x, tr.x, bl.x, br.x), lerp2(tl.y, tr.y, bl.y, br.y),
+            if (!UP2) {
+                const unsigned off = nbase[i] + (unsigned)iy * rowb + (unsigned)ix * pixb + cofs;
+                ra[i] = bload4(xrs, ok ? off : IG_OOB, 0);
+            } else {
+                // tf.image.resize_bilinear(src, 2x), legacy mapping src = dst * 0.5 (ICNET_SPEC "bilinear resize");
+                // out-of-image taps read four zeros and interpolate to an exact zero
+                const int y0 = iy >> 1, x0 = ix >> 1;
+                const int y1 = min(y0 + 1, Hs - 1), x1 = min(x0 + 1, Ws - 1);
+                const float ly = (iy & 1) ? 0.5f : 0.0f, lx = (ix & 1) ? 0.5f : 0.0f;
+                const unsigned b0 = nbase[i] + cofs;
+                const float4 tl = bload4(xrs, ok ? b0 + (unsigned)y0 * rowb + (unsigned)x0 * pixb : IG_OOB, 0);
+                const float4 tr = bload4(xrs, ok ? b0 + (unsigned)y0 * rowb + (unsigned)x1 * pixb : IG_OOB, 0);
+                const float4 bl = bload4(xrs, ok ? b0 + (unsigned)y1 * rowb + (unsigned)x0 * pixb : IG_OOB, 0);
+                const float4 br = bload4(xrs, ok ? b0 + (unsigned)y1 * rowb + (unsigned)x1 * pixb : IG_OOB, 0);
+                auto lerp2 = [&](float ctl, float ctr, float cbl, float cbr) {
+                    const float top = ctl + (ctr - ctl) * lx;
+                    const float bot = cbl + (cbr - cbl) * lx;
+                    return top + (bot - top) * ly;
+                };
+                ra[i] = make_float4(lerp2(tl.x, tr.x, bl.x, br.x), lerp2(tl.y, tr.y, bl.y, br.y),
                                     lerp2(tl.z, tr.z, bl.z, br.z), lerp2(tl.w, tr.w, bl.w, br.w));
-                }
             }
-            ra[i] = v;
         }
-        const float *wb = a.wt + ((long)t * a.CoutP + n0) * 32;
+        const unsigned wofs = (unsigned)(t * a.CoutP + n0) * 128u;  // wave-uniform
 #pragma unroll
-        for (int j = 0; j < NT; ++j) rb[j] = *reinterpret_cast<const float4 *>(wb + (long)(tid + 256 * j) * 4);
+        for (int j = 0; j < NT; ++j) rb[j] = bload4(wrs, 16u * (unsigned)(tid + 256 * j), wofs);
     };
     auto lds_write = [&](int buf) {
         float *As = smem + buf * (BM + BN) * LDK;
@@ -162,26 +170,32 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
     }
 
     // ---- epilogue: folded batch-norm, shortcut add, ReLU, store (128-B rows per lane half) --------
+    const unsigned ybytes = (unsigned)(a.M * a.Cout * 4);
+    const rsrc_t yrs = make_rsrc(a.y, ybytes);
+    const rsrc_t rrs = make_rsrc(a.res ? a.res : a.y, ybytes);
+    unsigned moff[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int m = m0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
+        moff[i] = m < M ? (unsigned)m * (unsigned)(a.Cout * 4) : IG_OOB;
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = n0 + 32 * nt + r;
         const float sc = a.scale[co], sh = a.shift[co];
         const bool cok = co < a.Cout;
         float rv[16];
-        if (a.res) {
+        if (a.res) {  // wave-uniform
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const long m = m0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
-                rv[i] = (cok && m < a.M) ? a.res[m * a.Cout + co] : 0.0f;
-            }
+            for (int i = 0; i < 16; ++i) rv[i] = bload(rrs, (cok && moff[i] != IG_OOB) ? moff[i] + 4u * co : IG_OOB, 0);
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const long m = m0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
             float v = fmaf(acc[nt][i], sc, sh);
             if (a.res) v = v + rv[i];
             if (a.relu) v = v > 0.0f ? v : 0.0f;
-            if (cok && m < a.M) a.y[m * a.Cout + co] = v;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs,
+                                                  (cok && moff[i] != IG_OOB) ? moff[i] + 4u * co : IG_OOB, 0, 0);
         }
     }
 }
@@ -229,6 +243,9 @@ hipError_t launch_igemm(const float *x, int N, int H, int W, int Cin, const floa
     a.pad_t = th / 2;
     a.pad_l = tw / 2;
     a.M = (long)N * a.Ho * a.Wo;
+    // 32-bit byte offsets inside the kernel: every tensor of one launch must stay below 4 GiB (split the batch)
+    if ((long)N * H * W * Cin * 4 >= (1L << 32) - 256 || a.M * Cout * 4 >= (1L << 32) - 256 || a.M >= (1L << 31) - 256)
+        return hipErrorInvalidValue;
     a.tiles_m = cdiv_i(a.M, IG_BM);
     const int nb32 = a.CoutP / 32;
     // widest column tile that divides the padded channel count and still leaves >= 2 workgroups per CU
@@ -241,10 +258,14 @@ hipError_t launch_igemm(const float *x, int N, int H, int W, int Cin, const floa
     const double flops = 2.0 * (double)a.M * KH * KW * Cin * Cout;
     const double bytes = 4.0 * ((double)N * H * W * Cin + (double)a.M * Cout * (res ? 2.0 : 1.0) +
                                 (double)KH * KW * Cin * Cout);
-    ProfScope prof(up2 ? "k_igemm_up2" : "k_igemm", flops, bytes, s);
-    if (NT == 4) hipLaunchKernelGGL(k_igemm<4>, dim3(grid), dim3(256), 0, s, a);
-    else if (NT == 2) hipLaunchKernelGGL(k_igemm<2>, dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_igemm<1>, dim3(grid), dim3(256), 0, s, a);
+    ProfScope prof(NT == 4 ? "k_igemm<4>" : NT == 2 ? "k_igemm<2>" : "k_igemm<1>", flops, bytes, s);
+#define SSAL_IG(N_)                                                                         \
+    if (up2) hipLaunchKernelGGL((k_igemm<N_, true>), dim3(grid), dim3(256), 0, s, a);      \
+    else hipLaunchKernelGGL((k_igemm<N_, false>), dim3(grid), dim3(256), 0, s, a)
+    if (NT == 4) { SSAL_IG(4); }
+    else if (NT == 2) { SSAL_IG(2); }
+    else { SSAL_IG(1); }
+#undef SSAL_IG
     return hipGetLastError();
 }
 

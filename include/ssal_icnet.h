@@ -74,7 +74,8 @@ int ssal_conv_bn_act(const float *x_dev, int n, int h, int w, int cin, const flo
 /* tf.nn.max_pool(x, 3x3, strides 2, "SAME") -> [n, ceil(h/2), ceil(w/2), c];  c % 4 == 0 */
 int ssal_max_pool_3x3_s2(const float *x_dev, int n, int h, int w, int c, float *y_dev, void *stream);
 /* ICNET_SPEC pyramid pooling: y = x + sum over b in (1,2,3,6) of resize_bilinear(bin_average_b(x), h, w);
- * ws >= n * 50 * c * 4 bytes; c % 4 == 0 */
+ * (bin average = sum over the bin's rows of the sum over its columns, divided by the count);
+ * ws >= n * (50 + 12 * h) * c * 4 bytes; c % 4 == 0 */
 int ssal_pyramid_pooling(const float *x_dev, int n, int h, int w, int c, float *y_dev, void *ws_dev, int64_t ws_bytes,
                          void *stream);
 /* conv6_interp + score on materialised 1/4-resolution logits lq_dev [n,h,w,classes]: outputs at [n,4h,4w] */

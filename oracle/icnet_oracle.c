@@ -93,7 +93,8 @@ ORC_API void orc_resize_bilinear(const float *x, int N, int H, int W, int C, int
 }
 
 /* Pyramid pooling bin average (ICNET_SPEC conv5_3_pool{1,2,3,6}): bin (i, j) of a b x b grid covers rows
- * [floor(i*H/b), ceil((i+1)*H/b)) and columns likewise; fp32 sum in row-major order divided by the count. */
+ * [floor(i*H/b), ceil((i+1)*H/b)) and columns likewise; value = (sum over the rows, ascending, of the row's sum over
+ * the columns, ascending) / count, all fp32. */
 ORC_API void orc_adaptive_avg_pool(const float *x, int N, int H, int W, int C, int b, float *y /* [N,b,b,C] */)
 {
 #pragma omp parallel for collapse(2) schedule(static)
@@ -105,8 +106,11 @@ ORC_API void orc_adaptive_avg_pool(const float *x, int N, int H, int W, int C, i
                 const float cnt = (float)((y1 - y0) * (x1 - x0));
                 for (int c = 0; c < C; ++c) {
                     float s = 0.0f;
-                    for (int yy = y0; yy < y1; ++yy)
-                        for (int xx = x0; xx < x1; ++xx) s += x[(((size_t)n * H + yy) * W + xx) * C + c];
+                    for (int yy = y0; yy < y1; ++yy) {
+                        float rs = 0.0f;
+                        for (int xx = x0; xx < x1; ++xx) rs += x[(((size_t)n * H + yy) * W + xx) * C + c];
+                        s += rs;
+                    }
                     y[(((size_t)n * b + i) * b + j) * C + c] = s / cnt;
                 }
             }

@@ -40,8 +40,9 @@ hipError_t launch_conv_first(const void *x, bool x_is_u8, int N, int H, int W, i
 // tf.nn.max_pool(3x3, stride 2, SAME); C % 4 == 0
 hipError_t launch_maxpool3x3_s2(const float *x, int N, int H, int W, int C, float *y, hipStream_t s);
 
-// pyramid pooling (ICNET_SPEC conv5_3_pool* / conv5_3_sum): pooled = [N][50 bins][C] scratch
-hipError_t launch_ppm(const float *x, int N, int H, int W, int C, float *pooled, float *y, hipStream_t s);
+// pyramid pooling (ICNET_SPEC conv5_3_pool* / conv5_3_sum): scratch = ppm_scratch_floats(N, H, C) floats
+int64_t ppm_scratch_floats(int N, int H, int C);
+hipError_t launch_ppm(const float *x, int N, int H, int W, int C, float *scratch, float *y, hipStream_t s);
 
 // conv6_interp (4x bilinear, legacy mapping) fused with the acquisition score (active_learning.py:234-263):
 // lq = 1/4-resolution logits [N,H,W,K]; outputs at [N,4H,4W]; partial: [N * upscore_blocks(H,W)] doubles

@@ -175,7 +175,7 @@ IcWorkspace carve(const ssal_icnet *net, void *ws, int64_t ws_bytes, int64_t n, 
     for (const ActSpec &a : net->acts) {
         W.act[a.name] = b.take<float>(n * (h / a.div) * (w / a.div) * a.c);
     }
-    W.pooled = b.take<float>(n * 50 * 1024);
+    W.pooled = b.take<float>(ppm_scratch_floats((int)n, (int)(h / 32), 1024));
     W.partial = b.take<double>(n * (int64_t)upscore_blocks((int)(h / 4), (int)(w / 4)));
     W.bytes = b.off;
     W.ok = b.ok;
@@ -553,7 +553,8 @@ SSAL_API int ssal_pyramid_pooling(const float *x_dev, int n, int h, int w, int c
 {
     if (!x_dev || !y_dev || !ws_dev) return fail(SSAL_EINVAL, "NULL device pointer");
     if (n <= 0 || h <= 0 || w <= 0 || c <= 0 || c % 4) return fail(SSAL_EINVAL, "bad dims");
-    if (ws_bytes < (int64_t)n * 50 * c * 4) return fail(SSAL_ENOMEM, "workspace too small: need %lld bytes", (long long)n * 50 * c * 4);
+    if (ws_bytes < ppm_scratch_floats(n, h, c) * 4)
+        return fail(SSAL_ENOMEM, "workspace too small: need %lld bytes", (long long)ppm_scratch_floats(n, h, c) * 4);
     HIP_TRY(launch_ppm(x_dev, n, h, w, c, (float *)ws_dev, y_dev, (hipStream_t)stream));
     return SSAL_OK;
 }

@@ -279,52 +279,92 @@ hipError_t launch_igemm(const float *x, int N, int H, int W, int Cin, const floa
 __device__ __forceinline__ float to_unit_f(float v) { return v; }
 __device__ __forceinline__ float to_unit_f(uint8_t v) { return (float)v * (1.0f / 255.0f); }
 
+// Workgroup = 8 x 32 output pixels of one image.  The 17 x 65 x CIN input window is staged once through LDS with
+// coalesced loads (uint8 frames are converted on the way); every thread then owns one output pixel: 27 LDS reads
+// against 27 x 32 FMAs whose kernel taps are wave-uniform (scalar loads).  The 32 output channels of a pixel are
+// 128 contiguous bytes, but a pixel per lane would make every store instruction touch 64 different lines, so the tile
+// goes back through LDS and leaves as 1-KB contiguous float4 stores.
+constexpr int CF_TH = 8, CF_TW = 32, CF_IH = 2 * CF_TH + 1, CF_IW = 2 * CF_TW + 1, CF_OS = 36;
+
 template <int CIN, typename TX>
 __global__ __launch_bounds__(256) void k_conv_first(const TX *__restrict__ x, const float *__restrict__ w,
                                                     const float *__restrict__ scale, const float *__restrict__ shift,
-                                                    float *__restrict__ y, int N, int H, int W, int sub)
+                                                    float *__restrict__ y, int N, int H, int W, int sub, int tiles_x,
+                                                    int tiles_y)
 {
     constexpr int CO = 32;
+    __shared__ float xin[CF_IH * CF_IW * CIN];
+    __shared__ __attribute__((aligned(16))) float xout[256 * CF_OS];
     const int Hc = H / sub, Wc = W / sub;          // dims of the conv input
     const int Ho = (Hc + 1) / 2, Wo = (Wc + 1) / 2;
     int th = (Ho - 1) * 2 + 3 - Hc; if (th < 0) th = 0;
     int tw = (Wo - 1) * 2 + 3 - Wc; if (tw < 0) tw = 0;
     const int pt = th / 2, pl = tw / 2;
-    const long total = (long)N * Ho * Wo;
-    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < total; p += (long)gridDim.x * 256) {
-        const int ox = (int)(p % Wo);
-        const int oy = (int)((p / Wo) % Ho);
-        const long n = p / ((long)Wo * Ho);
-        float acc[CO];
+    const int tile = blockIdx.x;
+    const int tx0 = (tile % tiles_x) * CF_TW;
+    const int ty0 = ((tile / tiles_x) % tiles_y) * CF_TH;
+    const long n = tile / (tiles_x * tiles_y);
+    const int tid = threadIdx.x;
+
+    // ---- stage the input window (zeros outside the conv input: SAME padding) ----------------------
+    // all loads of the window are issued before the first one is consumed (unconditional loads from a clamped
+    // address, zero selected afterwards): a load-then-store loop would pay one memory round trip per iteration
+    const int iy0 = 2 * ty0 - pt, ix0 = 2 * tx0 - pl;
+    constexpr int E = CF_IH * CF_IW * CIN, IT = (E + 255) / 256;
+    float stage[IT];
 #pragma unroll
-        for (int c = 0; c < CO; ++c) acc[c] = 0.0f;
+    for (int it = 0; it < IT; ++it) {
+        const int e = min(tid + 256 * it, E - 1);
+        const int ci = e % CIN;
+        const int rx = (e / CIN) % CF_IW;
+        const int ry = e / (CIN * CF_IW);
+        const int iy = iy0 + ry, ix = ix0 + rx;
+        const bool ok = iy >= 0 && iy < Hc && ix >= 0 && ix < Wc;
+        const int iyc = min(max(iy, 0), Hc - 1), ixc = min(max(ix, 0), Wc - 1);
+        const float v = to_unit_f(x[((n * H + (long)iyc * sub) * W + (long)ixc * sub) * CIN + ci]);
+        stage[it] = ok ? v : 0.0f;
+    }
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int iy = 2 * oy - pt + kh;
+    for (int it = 0; it < IT; ++it)
+        if (tid + 256 * it < E) xin[tid + 256 * it] = stage[it];
+    __syncthreads();
+
+    const int lx = tid & 31, ly = tid >> 5;
+    float acc[CO];
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int ix = 2 * ox - pl + kw;
-                const bool ok = iy >= 0 && iy < Hc && ix >= 0 && ix < Wc;
-                const TX *xp = x + ((n * H + (long)iy * sub) * W + (long)ix * sub) * CIN;
+    for (int c = 0; c < CO; ++c) acc[c] = 0.0f;
 #pragma unroll
-                for (int ci = 0; ci < CIN; ++ci) {
-                    const float xv = ok ? to_unit_f(xp[ci]) : 0.0f;
-                    const float *wr = w + ((kh * 3 + kw) * CIN + ci) * CO;
+    for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                    for (int co = 0; co < CO; ++co) acc[co] = fmaf(xv, wr[co], acc[co]);
-                }
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) {
+                const float xv = xin[((2 * ly + kh) * CF_IW + 2 * lx + kw) * CIN + ci];
+                const float *wr = w + ((kh * 3 + kw) * CIN + ci) * CO;
+#pragma unroll
+                for (int co = 0; co < CO; ++co) acc[co] = fmaf(xv, wr[co], acc[co]);
             }
+    // ---- folded batch-norm + ReLU, then through LDS so that the stores are contiguous --------------
+#pragma unroll
+    for (int q = 0; q < CO / 4; ++q) {
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float v = fmaf(acc[4 * q + k], scale[4 * q + k], shift[4 * q + k]);
+            o[k] = v > 0.0f ? v : 0.0f;
         }
-        float4 *yp = reinterpret_cast<float4 *>(y + p * CO);
+        *reinterpret_cast<float4 *>(xout + tid * CF_OS + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    __syncthreads();
+    // thread -> (tile row = tid >> 5 (+ 8 rows per pass? no: 256 float4 per pass = 32 pixels = one tile row))
 #pragma unroll
-        for (int q = 0; q < CO / 4; ++q) {
-            float o[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float v = fmaf(acc[4 * q + k], scale[4 * q + k], shift[4 * q + k]);
-                o[k] = v > 0.0f ? v : 0.0f;
-            }
-            yp[q] = make_float4(o[0], o[1], o[2], o[3]);
+    for (int j = 0; j < 8; ++j) {
+        const int f = j * 256 + tid;         // float4 index inside the tile: [8 rows][32 px][8 quads]
+        const int q = f & 7, px = (f >> 3) & 31, row = f >> 8;
+        const int oy = ty0 + row, ox = tx0 + px;
+        if (oy < Ho && ox < Wo) {
+            const float4 v = *reinterpret_cast<const float4 *>(xout + (row * 32 + px) * CF_OS + 4 * q);
+            *reinterpret_cast<float4 *>(y + ((n * Ho + oy) * (long)Wo + ox) * CO + 4 * q) = v;
         }
     }
 }
@@ -334,19 +374,21 @@ hipError_t launch_conv_first(const void *x, bool x_is_u8, int N, int H, int W, i
 {
     if (sub != 1 && sub != 2) return hipErrorInvalidValue;
     const int Hc = H / sub, Wc = W / sub;
-    const long total = (long)N * ((Hc + 1) / 2) * ((Wc + 1) / 2);
-    int grid = cdiv_i(total, 256);
-    if (grid > 1 << 20) grid = 1 << 20;
+    const int Ho = (Hc + 1) / 2, Wo = (Wc + 1) / 2;
+    const long total = (long)N * Ho * Wo;
+    const int tiles_x = cdiv_i(Wo, CF_TW), tiles_y = cdiv_i(Ho, CF_TH);
+    const long grid = (long)N * tiles_x * tiles_y;
+    if (grid >= (1L << 31)) return hipErrorInvalidValue;
     ProfScope prof("k_conv_first", 2.0 * (double)total * 9 * Cin * 32,
-                   (double)N * H * W * Cin * (x_is_u8 ? 1.0 : 4.0) / (sub * sub) + 4.0 * (double)total * 32, s);
+                   (double)N * H * W * Cin * (x_is_u8 ? 1.0 : 4.0) / sub + 4.0 * (double)total * 32, s);
 #define SSAL_CF(C)                                                                                                   \
     case C:                                                                                                          \
         if (x_is_u8)                                                                                                 \
-            hipLaunchKernelGGL((k_conv_first<C, uint8_t>), dim3(grid), dim3(256), 0, s, (const uint8_t *)x, w, scale, \
-                               shift, y, N, H, W, sub);                                                              \
+            hipLaunchKernelGGL((k_conv_first<C, uint8_t>), dim3((unsigned)grid), dim3(256), 0, s, (const uint8_t *)x, w, \
+                               scale, shift, y, N, H, W, sub, tiles_x, tiles_y);                                     \
         else                                                                                                         \
-            hipLaunchKernelGGL((k_conv_first<C, float>), dim3(grid), dim3(256), 0, s, (const float *)x, w, scale,     \
-                               shift, y, N, H, W, sub);                                                              \
+            hipLaunchKernelGGL((k_conv_first<C, float>), dim3((unsigned)grid), dim3(256), 0, s, (const float *)x, w,  \
+                               scale, shift, y, N, H, W, sub, tiles_x, tiles_y);                                     \
         break;
     switch (Cin) {
         SSAL_CF(1) SSAL_CF(3) SSAL_CF(4)
@@ -407,31 +449,63 @@ hipError_t launch_maxpool3x3_s2(const float *x, int N, int H, int W, int C, floa
 
 // ------------------------------------------------------------------------------------------------
 // Pyramid pooling (ICNET_SPEC conv5_3_pool{1,2,3,6}, conv5_3_sum).  Bins: b = 1 -> slot 0, b = 2 -> 1..4,
-// b = 3 -> 5..13, b = 6 -> 14..49.  k_ppm_pool: one thread per (image, bin, channel), fp32 sum in row-major order
-// divided by the count (the oracle's order).  k_ppm_sum: y = ((((x + up1) + up2) + up3) + up6), each up_b the
+// b = 3 -> 5..13, b = 6 -> 14..49.  Bin average = (sum over the bin's rows of (sum over the bin's columns)) / count,
+// both sums fp32 in ascending order (the oracle's order): k_ppm_rowsum forms the column sums of every row for the 12
+// column ranges, k_ppm_pool adds the rows of each bin -- two short, wide launches instead of one thread walking a whole
+// 32 x 64 map.  k_ppm_sum: y = ((((x + up1) + up2) + up3) + up6), each up_b the
 // legacy-mapped bilinear resize of the b x b bin grid back to H x W.
 // ------------------------------------------------------------------------------------------------
 __device__ __host__ constexpr int ppm_bins(int k) { return k == 0 ? 1 : k == 1 ? 2 : k == 2 ? 3 : 6; }
 __device__ __host__ constexpr int ppm_base(int k) { return k == 0 ? 0 : k == 1 ? 1 : k == 2 ? 5 : 14; }
 constexpr int PPM_SLOTS = 50;
 
-__global__ __launch_bounds__(256) void k_ppm_pool(const float *__restrict__ x, int N, int H, int W, int C,
-                                                  float *__restrict__ pooled)
+// column-bin slots of one row: b = 1 -> 0, b = 2 -> 1..2, b = 3 -> 3..5, b = 6 -> 6..11
+__device__ __host__ constexpr int ppm_cbase(int k) { return k == 0 ? 0 : k == 1 ? 1 : k == 2 ? 3 : 6; }
+constexpr int PPM_CSLOTS = 12;
+
+// stage 1: rowsum[n][y][cslot][c] = sum over the slot's columns (ascending) of x[n][y][.][c]
+__global__ __launch_bounds__(256) void k_ppm_rowsum(const float4 *__restrict__ x, int N, int H, int W, int C4,
+                                                    float4 *__restrict__ rowsum)
 {
-    const long total = (long)N * PPM_SLOTS * C;
+    const long total = (long)N * H * PPM_CSLOTS * C4;
     for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
-        const int c = (int)(o % C);
-        const int slot = (int)((o / C) % PPM_SLOTS);
-        const long n = o / ((long)C * PPM_SLOTS);
+        const int c = (int)(o % C4);
+        const int cs = (int)((o / C4) % PPM_CSLOTS);
+        const long ny = o / ((long)C4 * PPM_CSLOTS);  // n*H + y
+        const int k = cs >= 6 ? 3 : cs >= 3 ? 2 : cs >= 1 ? 1 : 0;
+        const int b = ppm_bins(k), j = cs - ppm_cbase(k);
+        const int x0 = (j * W) / b, x1 = ((j + 1) * W + b - 1) / b;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 *row = x + ny * W * C4 + c;
+        for (int xx = x0; xx < x1; ++xx) {
+            const float4 v = row[(long)xx * C4];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        rowsum[o] = s;
+    }
+}
+
+// stage 2: pooled[n][slot][c] = (sum over the bin's rows (ascending) of its row sums) / count
+__global__ __launch_bounds__(256) void k_ppm_pool(const float4 *__restrict__ rowsum, int N, int H, int W, int C4,
+                                                  float4 *__restrict__ pooled)
+{
+    const long total = (long)N * PPM_SLOTS * C4;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
+        const int c = (int)(o % C4);
+        const int slot = (int)((o / C4) % PPM_SLOTS);
+        const long n = o / ((long)C4 * PPM_SLOTS);
         const int k = slot >= 14 ? 3 : slot >= 5 ? 2 : slot >= 1 ? 1 : 0;
         const int b = ppm_bins(k), idx = slot - ppm_base(k);
         const int i = idx / b, j = idx % b;
         const int y0 = (i * H) / b, y1 = ((i + 1) * H + b - 1) / b;
         const int x0 = (j * W) / b, x1 = ((j + 1) * W + b - 1) / b;
-        float sum = 0.0f;
-        for (int yy = y0; yy < y1; ++yy)
-            for (int xx = x0; xx < x1; ++xx) sum += x[((n * H + yy) * W + xx) * C + c];
-        pooled[o] = sum / (float)((y1 - y0) * (x1 - x0));
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int yy = y0; yy < y1; ++yy) {
+            const float4 v = rowsum[((n * H + yy) * PPM_CSLOTS + ppm_cbase(k) + j) * C4 + c];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const float cnt = (float)((y1 - y0) * (x1 - x0));
+        pooled[o] = make_float4(s.x / cnt, s.y / cnt, s.z / cnt, s.w / cnt);
     }
 }
 
@@ -471,13 +545,24 @@ __global__ __launch_bounds__(256) void k_ppm_sum(const float4 *__restrict__ x, c
     }
 }
 
-hipError_t launch_ppm(const float *x, int N, int H, int W, int C, float *pooled, float *y, hipStream_t s)
+int64_t ppm_scratch_floats(int N, int H, int C) { return (int64_t)N * (PPM_SLOTS + (int64_t)PPM_CSLOTS * H) * C; }
+
+hipError_t launch_ppm(const float *x, int N, int H, int W, int C, float *scratch, float *y, hipStream_t s)
 {
     if (C % 4) return hipErrorInvalidValue;
+    float *pooled = scratch;                               // [N][50][C]
+    float *rowsum = scratch + (int64_t)N * PPM_SLOTS * C;  // [N][H][12][C]
     {
-        const long total = (long)N * PPM_SLOTS * C;
-        ProfScope prof("k_ppm_pool", 0.0, 4.0 * 4.0 * (double)N * H * W * C, s);
-        hipLaunchKernelGGL(k_ppm_pool, dim3(cdiv_i(total, 256)), dim3(256), 0, s, x, N, H, W, C, pooled);
+        const long total = (long)N * H * PPM_CSLOTS * (C / 4);
+        ProfScope prof("k_ppm_rowsum", 0.0, 4.0 * (4.0 * N * H * W * C + (double)total * 4), s);
+        hipLaunchKernelGGL(k_ppm_rowsum, dim3(cdiv_i(total, 256)), dim3(256), 0, s, (const float4 *)x, N, H, W, C / 4,
+                           (float4 *)rowsum);
+    }
+    {
+        const long total = (long)N * PPM_SLOTS * (C / 4);
+        ProfScope prof("k_ppm_pool", 0.0, 4.0 * 4.0 * (double)N * H * PPM_CSLOTS * C, s);
+        hipLaunchKernelGGL(k_ppm_pool, dim3(cdiv_i(total, 256)), dim3(256), 0, s, (const float4 *)rowsum, N, H, W, C / 4,
+                           (float4 *)pooled);
     }
     const long total = (long)N * H * W * (C / 4);
     int grid = cdiv_i(total, 256);

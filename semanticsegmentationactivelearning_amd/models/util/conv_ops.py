@@ -71,7 +71,7 @@ def pyramid_pooling(x):
     n, h, w, c = x.shape
     y = torch.empty_like(x)
     with torch.cuda.device(x.device):
-        ws = torch.empty(n * 50 * c * 4, dtype=torch.uint8, device=x.device)
+        ws = torch.empty(n * (50 + 12 * h) * c * 4, dtype=torch.uint8, device=x.device)
         _lib.check(_lib.lib().ssal_pyramid_pooling(_lib.dev_ptr(x), n, h, w, c, _lib.dev_ptr(y), _lib.dev_ptr(ws),
                                                    ws.numel(), _lib.stream_ptr()))
     return y

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "ssal_measure.h"
+
 namespace ssal {
 
 // One fused convolution of ICNET_SPEC.md: conv (SAME, no bias) -> folded batch-norm (scale, shift) -> [+ res] -> [relu].
@@ -21,6 +23,10 @@ struct IgemmArgs {
     long M;              // N*Ho*Wo
     int tiles_m, tiles_n;
     int ntiles, xcd_chunk;  // XCD-aware tile order: tile = (b % 8) * xcd_chunk + b / 8 (xcd_chunk = 0: tile = b)
+    unsigned long long *trace;  // phase-trace buffer (NULL unless a -DSSAL_PHASE_TRACE build is being traced)
+#ifdef SSAL_MEASURE
+    int ablate;  // measurement builds only: bit 0 = no MFMAs, bit 1 = no global loads, bit 2 = no LDS writes
+#endif
 };
 
 // kernel [KH][KW][Cin][Cout] (HWIO) -> [KH*KW][Cin/32][CoutP][32], CoutP = Cout rounded up to 32 (zero rows)

@@ -12,6 +12,7 @@
 // (kh, kw, ci) ascending -- the fp32 MFMA is exactly such a chain over its k index -- so results equal the parity
 // oracle bit for bit.  Out-of-image taps contribute fmaf(0, w, acc) == acc.
 #include "ssal_icnet.h"
+#include "ssal_internal.h"
 #include "ssal_mfma.h"
 #include "ssal_prof.h"
 #include "ssal_score.h"
@@ -31,11 +32,15 @@ static inline int cdiv_i(long a, long b) { return (int)((a + b - 1) / b); }
 // x 128 B (one full line per pixel, coalesced), the B chunk is 32*NT rows x 128 B, contiguous in the re-laid-out
 // kernel [tap][Cin/32][CoutP][32].  Both go global -> registers -> LDS (two buffers: the loads of chunk t+1 are in
 // flight while chunk t is multiplied), rows padded to 36 floats so that the ds_read_b128 fragment reads
-// (lane = row, 4 consecutive k per lane half) are bank-conflict free.  A lane's float4 holds k = 4h..4h+3 of an
-// 8-k group; v_permlane32_swap re-pairs the registers into the (k, k+1) lane-half pairs the MFMA consumes, in
-// ascending k order (ssal_mfma.h), so no LDS transpose is needed.
+// (lane = row, one quad per lane half) are bank-conflict free.  The k order inside a row is permuted (igemm_kpos) so
+// that the quad a lane half reads is already the MFMA operand sequence in ascending k order.
 // ------------------------------------------------------------------------------------------------
 constexpr int IG_BM = 128, IG_LDK = 36;
+// Position of channel k (0..31) inside a 32-channel chunk row, in LDS and in the re-laid-out kernel: every group of 8
+// is stored as [k0 k2 k4 k6 | k1 k3 k5 k7], so that ONE ds_read_b128 per lane half (h = 0: first quad, h = 1: second)
+// delivers, register by register, exactly the (k = 2s | k = 2s+1) lane-half pairs the MFMA steps s = 0..3 consume in
+// ascending k order -- no register re-pairing (v_permlane32_swap) between the read and the MFMA.
+__host__ __device__ constexpr int igemm_kpos(int k) { return (k & ~7) | ((k & 1) << 2) | ((k & 7) >> 1); }
 constexpr unsigned IG_OOB = 0xFFFFFFFFu;  // a byte offset no tensor reaches: raw buffer loads return 0, stores are dropped
 
 // Addressing: every tensor is reached through a raw buffer resource (base in SGPRs, range = tensor bytes) plus a
@@ -126,8 +131,13 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
         float *As = smem + buf * (BM + BN) * LDK;
         float *Bs = As + BM * LDK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<float4 *>(As + ((tid >> 3) + 32 * i) * LDK + 4 * col4) = ra[i];
+        for (int i = 0; i < 4; ++i) {
+            // channels 4*col4 .. +3 = (k, k+1, k+2, k+3) with k = 0 or 4 (mod 8): k and k+2 are neighbours in the
+            // permuted row, so are k+1 and k+3
+            float *ap = As + ((tid >> 3) + 32 * i) * LDK + 8 * (col4 >> 1) + 2 * (col4 & 1);
+            *reinterpret_cast<float2 *>(ap) = make_float2(ra[i].x, ra[i].z);
+            *reinterpret_cast<float2 *>(ap + 4) = make_float2(ra[i].y, ra[i].w);
+        }
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int idx = tid + 256 * j;
@@ -141,33 +151,72 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[nt][i] = 0.0f;
 
+#ifdef SSAL_PHASE_TRACE  // tools/igemm_trace.py: per-wave cycle totals of the phases of the K loop
+    unsigned long long tr_t0 = __builtin_amdgcn_s_memtime(), tr_r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tr_gl = 0, tr_mm = 0, tr_vm = 0, tr_wr = 0, tr_bar = 0, tr_a, tr_b;
+#define TR_MARK(acc_)  do { tr_b = __builtin_amdgcn_s_memtime(); acc_ += tr_b - tr_a; tr_a = tr_b; } while (0)
+#else
+#define TR_MARK(acc_)  do { } while (0)
+#endif
     gload(0);
     lds_write(0);
     __syncthreads();
+#ifdef SSAL_PHASE_TRACE
+    const unsigned long long tr_loop = __builtin_amdgcn_s_memtime();
+    tr_a = tr_loop;
+#endif
     for (int t = 0; t < nchunks; ++t) {
         const bool more = t + 1 < nchunks;
+#ifdef SSAL_MEASURE
+        if (more && !(a.ablate & 2)) gload(t + 1);
+#else
         if (more) gload(t + 1);
-        const float *As = smem + (t & 1) * (BM + BN) * LDK;
-        const float *Bs = As + BM * LDK;
+#endif
+        TR_MARK(tr_gl);
+        const float *As = smem + (t & 1) * (BM + BN) * LDK + (32 * wave + r) * LDK + 4 * h;
+        const float *Bs = smem + (t & 1) * (BM + BN) * LDK + BM * LDK + r * LDK + 4 * h;
+        // fragments of 8-k group g+1 are requested before the 4*NT MFMAs of group g: the LDS latency hides behind them
+        float4 af[2], bf[2][NT];
+        af[0] = *reinterpret_cast<const float4 *>(As);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bf[0][nt] = *reinterpret_cast<const float4 *>(Bs + 32 * nt * LDK);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            float4 af = *reinterpret_cast<const float4 *>(As + (32 * wave + r) * LDK + 8 * g + 4 * h);
-            swap32(af.x, af.y);  // af.x = (k0 | k1), af.y = (k4 | k5)
-            swap32(af.z, af.w);  // af.z = (k2 | k3), af.w = (k6 | k7)
+#ifdef SSAL_MEASURE
+            if (a.ablate & 1) break;  // timing only: no fragment reads, no MFMAs
+#endif
+            const int c = g & 1, nx = c ^ 1;
+            if (g < 3) {
+                af[nx] = *reinterpret_cast<const float4 *>(As + 8 * (g + 1));
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    bf[nx][nt] = *reinterpret_cast<const float4 *>(Bs + 32 * nt * LDK + 8 * (g + 1));
+            }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                float4 bf = *reinterpret_cast<const float4 *>(Bs + (32 * nt + r) * LDK + 8 * g + 4 * h);
-                swap32(bf.x, bf.y);
-                swap32(bf.z, bf.w);
-                acc[nt] = mfma32(af.x, bf.x, acc[nt]);
-                acc[nt] = mfma32(af.z, bf.z, acc[nt]);
-                acc[nt] = mfma32(af.y, bf.y, acc[nt]);
-                acc[nt] = mfma32(af.w, bf.w, acc[nt]);
+                acc[nt] = mfma32(af[c].x, bf[c][nt].x, acc[nt]);
+                acc[nt] = mfma32(af[c].y, bf[c][nt].y, acc[nt]);
+                acc[nt] = mfma32(af[c].z, bf[c][nt].z, acc[nt]);
+                acc[nt] = mfma32(af[c].w, bf[c][nt].w, acc[nt]);
             }
         }
+        TR_MARK(tr_mm);
+#ifdef SSAL_PHASE_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TR_MARK(tr_vm);
+#endif
+#ifdef SSAL_MEASURE
+        if (more && !(a.ablate & 4)) lds_write((t + 1) & 1);
+#else
         if (more) lds_write((t + 1) & 1);
+#endif
+        TR_MARK(tr_wr);
         __syncthreads();
+        TR_MARK(tr_bar);
     }
+#ifdef SSAL_PHASE_TRACE
+    const unsigned long long tr_loop_end = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- epilogue: folded batch-norm, shortcut add, ReLU, store (128-B rows per lane half) --------
     const unsigned ybytes = (unsigned)(a.M * a.Cout * 4);
@@ -198,6 +247,17 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
                                                   (cok && moff[i] != IG_OOB) ? moff[i] + 4u * co : IG_OOB, 0, 0);
         }
     }
+#ifdef SSAL_PHASE_TRACE
+    if (a.trace && lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long *p = a.trace + ((long)blockIdx.x * 4 + wave) * 16;
+        p[0] = tr_t0; p[1] = tr_loop; p[2] = tr_gl; p[3] = tr_mm; p[4] = tr_vm; p[5] = tr_wr; p[6] = tr_bar;
+        p[7] = tr_loop_end; p[8] = __builtin_amdgcn_s_memtime(); p[9] = (unsigned long long)nchunks;
+        p[12] = tr_r0; p[13] = __builtin_amdgcn_s_memrealtime();
+        p[14] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+        p[15] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+    }
+#endif
 }
 
 size_t igemm_relayout_floats(int KH, int KW, int Cin, int Cout)
@@ -213,7 +273,8 @@ void igemm_relayout(const float *w, int KH, int KW, int Cin, int Cout, float *ou
     for (int tap = 0; tap < KH * KW; ++tap)
         for (int ci = 0; ci < Cin; ++ci)
             for (int co = 0; co < Cout; ++co)
-                out[(((size_t)tap * cpt + ci / 32) * CoutP + co) * 32 + ci % 32] = w[((size_t)tap * Cin + ci) * Cout + co];
+                out[(((size_t)tap * cpt + ci / 32) * CoutP + co) * 32 + igemm_kpos(ci % 32)] =
+                    w[((size_t)tap * Cin + ci) * Cout + co];
 }
 
 bool igemm_supported(int Cin, int Cout, int KH, int KW)
@@ -255,6 +316,10 @@ hipError_t launch_igemm(const float *x, int N, int H, int W, int Cin, const floa
     a.ntiles = a.tiles_m * a.tiles_n;
     a.xcd_chunk = (a.ntiles + 7) / 8;
     const int grid = a.xcd_chunk * 8;
+    a.trace = (g_trace_buf && (long)grid * 4 * 16 * 8 <= g_trace_bytes) ? g_trace_buf : nullptr;
+#ifdef SSAL_MEASURE
+    a.ablate = knobs().ablate;
+#endif
     const double flops = 2.0 * (double)a.M * KH * KW * Cin * Cout;
     const double bytes = 4.0 * ((double)N * H * W * Cin + (double)a.M * Cout * (res ? 2.0 : 1.0) +
                                 (double)KH * KW * Cin * Cout);

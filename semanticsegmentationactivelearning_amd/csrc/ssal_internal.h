@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "ssal_measure.h"
+
 namespace ssal {
 
 // How the residual branch of an ENet bottleneck is merged in the epilogue of the expansion conv.

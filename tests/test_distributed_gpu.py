@@ -1,0 +1,70 @@
+"""The sharded ranking pass with REAL scores: two ranks (one process each, sharing the one GPU of the box,
+collectives over gloo) score their `shard_positions` shard of a small synthetic pool with `ENet.score` through
+`rank_confidence`, and every rank must select exactly the examples the single-process oracle selects.  What this
+cannot exercise is RCCL itself (one GPU): the collective here runs on CPU tensors."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+NUM, K, H, W, BS = 22, 6, 32, 64, 4  # 22 examples over 2 ranks: 11 each, last batch short
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from helpers import make_model
+    from semanticsegmentationactivelearning_amd import active_learning as al, synthetic as syn
+    from test_distributed_cpu import _CollectiveCounter
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        net, _ = make_model(19, 3, seed=0)
+        pos = al.shard_positions(NUM, rank, world)
+        mine = pos[pos >= 0]
+        batches = [(syn.synth_frames_f32(mine[i:i + BS] + 100, H, W, 3), mine[i:i + BS]) for i in range(0, len(mine), BS)]
+        unlabelled = np.arange(NUM)[np.arange(NUM) % 4 != 1]
+        with _CollectiveCounter() as cc:
+            low, uconf = al.rank_confidence(net, batches, NUM, unlabelled, K, measure="entropy")
+        assert cc.calls == ["all_gather_into_tensor"], cc.calls  # ONE collective per ranking pass
+        np.save(os.path.join(out_dir, "low_%d.npy" % rank), np.sort(low))
+        np.save(os.path.join(out_dir, "uc_%d.npy" % rank), uconf)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_real_scores_match_oracle(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import frames, make_model
+    from oracle import enet_oracle as orc
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    lows = [np.load(tmp_path / ("low_%d.npy" % r)) for r in range(world)]
+    ucs = [np.load(tmp_path / ("uc_%d.npy" % r)) for r in range(world)]
+    assert (lows[0] == lows[1]).all() and (ucs[0] == ucs[1]).all()  # identical selection on every rank
+    _, P = make_model(19, 3, seed=0)
+    want_mean = orc.score_images(P, frames(np.arange(NUM) + 100, H, W, 3), "entropy")[0]
+    unlabelled = np.arange(NUM)[np.arange(NUM) % 4 != 1]
+    want_low, want_u = orc.rank_lowest(want_mean, unlabelled, K)
+    srt = np.sort(want_u)
+    assert srt[K] - srt[K - 1] > 1e-5, "fixture must separate the k-th boundary"
+    assert sorted(want_low.tolist()) == lows[0].tolist()
+    assert np.abs(ucs[0] - want_u).max() <= 1e-6

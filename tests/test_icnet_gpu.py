@@ -159,7 +159,7 @@ def _check_net(net, P, x, tag, every_endpoint=True):
 
 
 def test_every_block_and_logits_bit_exact(icnet19):
-    """every materialised ICNET_SPEC layer output (69 tensors) + the logits, 2 frames of 64x128"""
+    """every materialised ICNET_SPEC layer output (67 tensors) + the logits, 2 frames of 64x128"""
     net, P = icnet19
     x = frames([0, 1], 64, 128, 3)
     got, want = _check_net(net, P, x, "64x128")
@@ -252,3 +252,17 @@ def test_full_resolution_frame_bit_exact(icnet19):
     want_mean, _, want_label = orc.score_logits(full, "margin")
     report_diff("label", e["label"].cpu().numpy(), want_label)
     report_diff("margin mean", s.cpu().numpy(), want_mean, exact=False, atol=1e-6)
+
+
+def test_matches_golden_fixture(icnet19):
+    import os
+    net, P = icnet19
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "icnet_c3k19_64x128.npz"))
+    x = frames(list(g["frame_ids"]), 64, 128, 3)
+    for m in ("margin", "entropy", "confidence"):
+        s, e = net.score(dev(x), m, return_label=True, return_confidence=True)
+        report_diff(m + " label vs golden", e["label"].cpu().numpy(), g["label"])
+        report_diff(m + " conf vs golden", e["confidence"].cpu().numpy()[0], g["conf_" + m], exact=False, atol=TOL)
+        report_diff(m + " mean vs golden", s.cpu().numpy(), g["mean_" + m], exact=False, atol=1e-6)
+    report_diff("1/4-resolution logits vs golden", net.endpoint("conv6_cls").cpu().numpy(), g["logits_quarter"])
+    report_diff("sub12_sum slice vs golden", net.endpoint("sub12_sum").cpu().numpy()[0, :4, :4, :], g["sub12_sum_slice"])

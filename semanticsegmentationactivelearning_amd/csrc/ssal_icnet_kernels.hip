@@ -51,6 +51,10 @@ template <int NT, bool UP2>
 __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
 {
     constexpr int BM = IG_BM, BN = 32 * NT, LDK = IG_LDK;
+    // The kernel tiles (B) are always stored permuted (free: done once at commit).  The activation tile (A) is
+    // permuted while it is written to LDS when that pays: two 8-byte LDS writes per quad instead of one 16-byte
+    // write, against 2 register swaps per fragment read -- a win when the fragment feeds several column tiles.
+    constexpr bool A_PERMUTED = NT >= 2;
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -132,11 +136,15 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
         float *Bs = As + BM * LDK;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            // channels 4*col4 .. +3 = (k, k+1, k+2, k+3) with k = 0 or 4 (mod 8): k and k+2 are neighbours in the
-            // permuted row, so are k+1 and k+3
-            float *ap = As + ((tid >> 3) + 32 * i) * LDK + 8 * (col4 >> 1) + 2 * (col4 & 1);
-            *reinterpret_cast<float2 *>(ap) = make_float2(ra[i].x, ra[i].z);
-            *reinterpret_cast<float2 *>(ap + 4) = make_float2(ra[i].y, ra[i].w);
+            if (A_PERMUTED) {
+                // channels 4*col4 .. +3 = (k, k+1, k+2, k+3) with k = 0 or 4 (mod 8): k and k+2 are neighbours in
+                // the permuted row, so are k+1 and k+3
+                float *ap = As + ((tid >> 3) + 32 * i) * LDK + 8 * (col4 >> 1) + 2 * (col4 & 1);
+                *reinterpret_cast<float2 *>(ap) = make_float2(ra[i].x, ra[i].z);
+                *reinterpret_cast<float2 *>(ap + 4) = make_float2(ra[i].y, ra[i].w);
+            } else {
+                *reinterpret_cast<float4 *>(As + ((tid >> 3) + 32 * i) * LDK + 4 * col4) = ra[i];
+            }
         }
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -191,6 +199,13 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     bf[nx][nt] = *reinterpret_cast<const float4 *>(Bs + 32 * nt * LDK + 8 * (g + 1));
+            }
+            if (!A_PERMUTED) {  // natural k order in the A rows: re-pair the registers of the ONE A fragment instead
+                swap32(af[c].x, af[c].y);  // .x = (k0 | k1), .y = (k4 | k5)
+                swap32(af[c].z, af[c].w);  // .z = (k2 | k3), .w = (k6 | k7)
+                const float t = af[c].y;
+                af[c].y = af[c].z;         // -> step order x, y, z, w = (k0|k1), (k2|k3), (k4|k5), (k6|k7)
+                af[c].z = t;
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {

@@ -334,7 +334,7 @@ hipError_t launch_convT(const float *x, int N, int H, int W, int Cin, const floa
 // wF = [3][3][16][K2], K2 = K rounded up to even (zero padded at commit): two classes per
 // v_pk_fma_f32 -- the kernel tap pair sits in an aligned SGPR pair, the activation is broadcast to both
 // halves (op_sel), each half is an ordinary IEEE fma, so the chain per class is unchanged.
-// grid = (ceil(H*W/256), N): a block never straddles two images.
+// grid = (ceil(H/16) * ceil(W/16), N): a workgroup owns a 16 x 16 tile of input pixels of one image, staged through LDS.
 // ------------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -396,6 +396,10 @@ struct FsTap {
     }
 };
 
+// Workgroup = 16 x 16 input pixels (= 32 x 32 output pixels) of one image; FS_PS = LDS floats per pixel (16 + 4 pad:
+// the ds_read_b128 of 16 neighbouring pixels then fall on 16 different bank quads).
+constexpr int FS_T = 16, FS_TP = FS_T + 1, FS_PS = 20;
+
 // OUT = false: score only (the ranking pass): logits / label / mask / conf are not touched, which frees the
 // SGPRs their pointers would pin and lets the kernel taps stream two input channels at a time.
 template <int K, bool OUT>
@@ -408,30 +412,50 @@ __global__ __launch_bounds__(256) void k_final_score(const float *__restrict__ x
                                                      float *__restrict__ conf)
 {
     __shared__ double red[4];
+    __shared__ __attribute__((aligned(16))) float tile[FS_TP * FS_TP * FS_PS];
     const int n = blockIdx.y;
     const long HW = (long)H * W;
-    const long p = (long)blockIdx.x * 256 + threadIdx.x;
-    const bool valid = p < HW;
-    double local = 0.0;
-    if (valid) {
-        const int i = (int)(p / W), j = (int)(p % W);
-        float va[16], vb[16], vc[16], vd[16];
-        const float *xa = x + ((long)n * HW + p) * 16;
+    const int tiles_x = (W + FS_T - 1) / FS_T;
+    const int i0 = (int)(blockIdx.x / tiles_x) * FS_T, j0 = (int)(blockIdx.x % tiles_x) * FS_T;
+    // ---- stage the (16+1) x (16+1) pixel window (one halo row above, one halo column to the left) through LDS:
+    // every input pixel is fetched once per workgroup with coalesced float4 loads; outside the image = zeros
+    // (the transposed conv has no contribution from there).  All loads are issued before the first LDS write.
+    {
+        constexpr int NQ = FS_TP * FS_TP * 4, IT = (NQ + 255) / 256;  // float4 quads of the window
+        float4 st[IT];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 t = reinterpret_cast<const float4 *>(xa)[q];
-            va[4 * q] = t.x; va[4 * q + 1] = t.y; va[4 * q + 2] = t.z; va[4 * q + 3] = t.w;
+        for (int it = 0; it < IT; ++it) {
+            const int e = min((int)threadIdx.x + 256 * it, NQ - 1);
+            const int q = e & 3, pj = (e >> 2) % FS_TP, pi = (e >> 2) / FS_TP;
+            const int gi = i0 - 1 + pi, gj = j0 - 1 + pj;
+            const bool ok = gi >= 0 && gi < H && gj >= 0 && gj < W;
+            const long gp = (long)min(max(gi, 0), H - 1) * W + min(max(gj, 0), W - 1);
+            const float4 t = reinterpret_cast<const float4 *>(x + ((long)n * HW + gp) * 16)[q];
+            st[it] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int e = (int)threadIdx.x + 256 * it;
+            if (e < NQ) *reinterpret_cast<float4 *>(tile + (e >> 2) * FS_PS + 4 * (e & 3)) = st[it];
+        }
+    }
+    __syncthreads();
+    const int ti = threadIdx.x / FS_T, tj = threadIdx.x % FS_T;
+    const int i = i0 + ti, j = j0 + tj;
+    const bool valid = i < H && j < W;
+    double local = 0.0;
+    if (valid) {
+        float va[16], vb[16], vc[16], vd[16];
+        const float *la = tile + ((ti + 1) * FS_TP + tj + 1) * FS_PS;  // own pixel; b = above, c = left, d = above-left
+#pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i > 0) t = reinterpret_cast<const float4 *>(xa - (long)W * 16)[q];
+            float4 t = reinterpret_cast<const float4 *>(la)[q];
+            va[4 * q] = t.x; va[4 * q + 1] = t.y; va[4 * q + 2] = t.z; va[4 * q + 3] = t.w;
+            t = reinterpret_cast<const float4 *>(la - FS_TP * FS_PS)[q];
             vb[4 * q] = t.x; vb[4 * q + 1] = t.y; vb[4 * q + 2] = t.z; vb[4 * q + 3] = t.w;
-            t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j > 0) t = reinterpret_cast<const float4 *>(xa - 16)[q];
+            t = reinterpret_cast<const float4 *>(la - FS_PS)[q];
             vc[4 * q] = t.x; vc[4 * q + 1] = t.y; vc[4 * q + 2] = t.z; vc[4 * q + 3] = t.w;
-            t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i > 0 && j > 0) t = reinterpret_cast<const float4 *>(xa - (long)W * 16 - 16)[q];
+            t = reinterpret_cast<const float4 *>(la - FS_TP * FS_PS - FS_PS)[q];
             vd[4 * q] = t.x; vd[4 * q + 1] = t.y; vd[4 * q + 2] = t.z; vd[4 * q + 3] = t.w;
         }
         const float inv_logK = 1.0f / __logf((float)K);
@@ -486,7 +510,7 @@ __global__ __launch_bounds__(256) void k_final_score(const float *__restrict__ x
     if (threadIdx.x == 0) partial[(long)n * gridDim.x + blockIdx.x] = r;
 }
 
-int final_score_blocks(int H, int W) { return cdiv((long)H * W, 256); }
+int final_score_blocks(int H, int W) { return cdiv(H, FS_T) * cdiv(W, FS_T); }
 
 hipError_t launch_final_score(const float *x, int N, int H, int W, const float *wF, int K,
                               float *logits, int measure, float threshold, double *partial,

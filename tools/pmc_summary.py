@@ -1,26 +1,34 @@
-"""Summarise the rocprofv3 --pmc passes (gpurun_out/pmc_*) into profiles/r01_pmc/: the raw
-counter_collection CSVs plus traffic.json = per-kernel average FETCH_SIZE / WRITE_SIZE per launch (KB)
+"""Summarise the rocprofv3 --pmc passes (gpurun_out/pmc_<model>_*) into profiles/<round>_pmc/: the raw
+counter_collection CSVs plus traffic_<model>.json = per-kernel average FETCH_SIZE / WRITE_SIZE per launch (KB)
 and the SQ pipe counters.  HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950
-FETCH_SIZE reports half the bytes of wide (16 B/lane) reads (MI355X_MICROARCH.md, HBM section)."""
+FETCH_SIZE reports half the bytes of wide (16 B/lane) reads (MI355X_MICROARCH.md, HBM section).
+Usage: python tools/pmc_summary.py [model=enet] [round=r02]"""
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out")
-DST = os.path.join(ROOT, "profiles", "r01_pmc")
+MODEL = sys.argv[1] if len(sys.argv) > 1 else "enet"
+ROUND = sys.argv[2] if len(sys.argv) > 2 else "r02"
+DST = os.path.join(ROOT, "profiles", "%s_pmc" % ROUND)
 os.makedirs(DST, exist_ok=True)
 
 
 def short(name):
+    """kernel names as ssal_profile_collect (bench.py's roofline leg) reports them"""
     n = name.split("(")[0].replace("void ", "").replace("ssal::", "")
-    return n.split("<")[0] if not n.startswith("k_bottleneck16") else n.replace(" ", "")
+    if n.startswith("k_bottleneck16"):
+        return n.replace(" ", "")
+    if n.startswith("k_igemm"):
+        return n.split(",")[0] + ">"  # k_igemm<4, true> -> k_igemm<4>
+    return n.split("<")[0]
 
 
 out = collections.defaultdict(dict)
 for pas, dst in (("sq", "sq_counters.csv"), ("fetch", "fetch_size.csv"), ("write", "write_size.csv"), ("lds", "lds_counters.csv")):
-    fs = sorted(glob.glob(os.path.join(SRC, "pmc_%s" % pas, "runc", "*_counter_collection.csv")), key=os.path.getmtime)
+    fs = sorted(glob.glob(os.path.join(SRC, "pmc_%s_%s" % (MODEL, pas), "runc", "*_counter_collection.csv")), key=os.path.getmtime)
     if not fs:
         continue
-    shutil.copy(fs[-1], os.path.join(DST, dst))
+    shutil.copy(fs[-1], os.path.join(DST, MODEL + "_" + dst))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(fs[-1])):
         agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -33,7 +41,7 @@ for pas, dst in (("sq", "sq_counters.csv"), ("fetch", "fetch_size.csv"), ("write
 for k, d in out.items():
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         d["hbm_bytes_per_launch"] = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
-json.dump(out, open(os.path.join(DST, "traffic.json"), "w"), indent=1, sort_keys=True)
+json.dump(out, open(os.path.join(DST, "traffic_%s.json" % MODEL), "w"), indent=1, sort_keys=True)
 for k in sorted(out):
     d = out[k]
     print("%-28s fetch %8.0f KB  write %8.0f KB  hbm/launch %7.1f MB  mfma_busy %.3g" % (

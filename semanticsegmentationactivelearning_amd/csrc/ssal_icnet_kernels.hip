@@ -275,6 +275,144 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / dilation 1 convolution on 32 input channels (conv1_2_3x3, conv1_3_3x3, conv2_x_3x3): the 9 taps of
+// neighbouring pixels read the same input pixels, so instead of re-staging a 128-pixel A chunk per tap (k_igemm) the
+// workgroup stages the (8+2) x (16+2) pixel window ONCE and then runs the 144 MFMAs of its K loop (9 taps x 32
+// channels) without a single global load or barrier: fragments are read from the window at the tap's offset.
+// Workgroups are persistent: the 9 x 32 x 32 kernel slice of their column tile is staged once, and the window of the
+// next spatial tile is requested before the K loop of the current one.  Same arithmetic order as k_igemm (taps ascending,
+// channels ascending), same permuted-k rows (no operand re-pairing), same epilogue.
+// Workgroup = 4 waves, tile = 8 x 16 output pixels x 32 output channels; wave w owns tile rows 2w, 2w+1.
+// LDS 67 KB = two workgroups per CU.
+// ------------------------------------------------------------------------------------------------
+constexpr int HT_H = 8, HT_W = 16, HT_WW = HT_W + 2, HT_WP = (HT_H + 2) * HT_WW;  // 180 window pixels
+
+struct HaloArgs {
+    const float *x, *wt, *scale, *shift, *res;
+    float *y;
+    int N, H, W, Cout, CoutP, relu;
+    int tiles_x, tiles_y, tiles_n;
+};
+
+__global__ __launch_bounds__(256) void k_conv3x3_c32(HaloArgs a)
+{
+    constexpr int LDK = IG_LDK;
+    __shared__ __attribute__((aligned(16))) float As[HT_WP * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[9 * 32 * LDK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    // persistent workgroup: keeps ONE column tile's kernel slice in LDS and walks spatial tiles
+    // sp = first, first + step, ...; the window of tile i+1 is in flight while tile i is multiplied
+    const int tn = blockIdx.x % a.tiles_n, n0 = tn * 32;
+    const int step = gridDim.x / a.tiles_n;
+    int sp = blockIdx.x / a.tiles_n;
+    const int nsp = a.N * a.tiles_y * a.tiles_x;
+    if (sp >= nsp) return;  // whole workgroup, before any barrier
+
+    const unsigned img = (unsigned)(a.H * a.W * 32 * 4);
+    const rsrc_t wrs = make_rsrc(a.wt, (unsigned)(9 * a.CoutP * 32 * 4));
+    constexpr int AQ = HT_WP * 8, AIT = (AQ + 255) / 256;  // float4 quads of the window
+    float4 sa[AIT];
+    auto decode = [&](int t, int &n, int &ty0, int &tx0) {
+        const int tx = t % a.tiles_x;
+        const int q = t / a.tiles_x;
+        tx0 = tx * HT_W;
+        ty0 = (q % a.tiles_y) * HT_H;
+        n = q / a.tiles_y;
+    };
+    auto load_window = [&](int t) {  // unconditional buffer loads; outside the image = out-of-range offset = zeros
+        int n, ty0, tx0;
+        decode(t, n, ty0, tx0);
+        const rsrc_t xrs = make_rsrc(a.x + (long)n * a.H * a.W * 32, img);
+#pragma unroll
+        for (int it = 0; it < AIT; ++it) {
+            const int e = tid + 256 * it;
+            const int px = min(e >> 3, HT_WP - 1), q = e & 7;
+            const int iy = ty0 - 1 + px / HT_WW, ix = tx0 - 1 + px % HT_WW;
+            const bool ok = e < AQ && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            sa[it] = bload4(xrs, ok ? (unsigned)((iy * a.W + ix) * 128 + 16 * q) : IG_OOB, 0);
+        }
+    };
+    load_window(sp);
+    {
+        float4 sb[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) sb[t] = bload4(wrs, 16u * (unsigned)tid, (unsigned)(t * a.CoutP + n0) * 128u);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            *reinterpret_cast<float4 *>(Bs + (t * 32 + (tid >> 3)) * LDK + 4 * (tid & 7)) = sb[t];
+    }
+    const float bsc = a.scale[n0 + r], bsh = a.shift[n0 + r];
+    const int co = n0 + r;
+    const bool cok = co < a.Cout;
+    const unsigned ybytes = (unsigned)(a.H * a.W * a.Cout * 4);
+    const int pr = 2 * wave + (r >> 4), pc = r & 15;
+    const float *Ab = As + (pr * HT_WW + pc) * LDK + 4 * h;
+    const float *Bb = Bs + r * LDK + 4 * h;
+
+    for (; sp < nsp; sp += step) {
+        int n, ty0, tx0;
+        decode(sp, n, ty0, tx0);
+        __syncthreads();  // every wave has finished reading the previous window
+#pragma unroll
+        for (int it = 0; it < AIT; ++it) {
+            const int e = tid + 256 * it;
+            if (e < AQ) {  // permuted-k row (igemm_kpos): (k, k+2) and (k+1, k+3) are neighbours
+                float *ap = As + (e >> 3) * LDK + 8 * ((e & 7) >> 1) + 2 * (e & 1);
+                *reinterpret_cast<float2 *>(ap) = make_float2(sa[it].x, sa[it].z);
+                *reinterpret_cast<float2 *>(ap + 4) = make_float2(sa[it].y, sa[it].w);
+            }
+        }
+        __syncthreads();
+        if (sp + step < nsp) load_window(sp + step);  // in flight during the K loop below
+
+        // ---- K loop: 9 taps x 4 groups of 8 channels, fragments one group ahead, no global load, no barrier ----
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        float4 af[2], bf[2];
+        af[0] = *reinterpret_cast<const float4 *>(Ab);
+        bf[0] = *reinterpret_cast<const float4 *>(Bb);
+#pragma unroll
+        for (int s = 0; s < 36; ++s) {  // s = tap * 4 + group
+            const int c = s & 1, nx = c ^ 1;
+            if (s + 1 < 36) {
+                const int t1 = (s + 1) >> 2, g1 = (s + 1) & 3;
+                af[nx] = *reinterpret_cast<const float4 *>(Ab + ((t1 / 3) * HT_WW + (t1 % 3)) * LDK + 8 * g1);
+                bf[nx] = *reinterpret_cast<const float4 *>(Bb + t1 * 32 * LDK + 8 * g1);
+            }
+            acc = mfma32(af[c].x, bf[c].x, acc);
+            acc = mfma32(af[c].y, bf[c].y, acc);
+            acc = mfma32(af[c].z, bf[c].z, acc);
+            acc = mfma32(af[c].w, bf[c].w, acc);
+        }
+
+        // ---- epilogue ------------------------------------------------------------------------------------
+        const rsrc_t yrs = make_rsrc(a.y + (long)n * a.H * a.W * a.Cout, ybytes);
+        const rsrc_t rrs = make_rsrc((a.res ? a.res : a.y) + (long)n * a.H * a.W * a.Cout, ybytes);
+        unsigned moff[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = (i & 3) + 8 * (i >> 2) + 4 * h;
+            const int oy = ty0 + 2 * wave + (m >> 4), ox = tx0 + (m & 15);
+            moff[i] = (cok && oy < a.H && ox < a.W) ? (unsigned)(((oy * a.W + ox) * a.Cout + co) * 4) : IG_OOB;
+        }
+        float rv[16];
+        if (a.res) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) rv[i] = bload(rrs, moff[i], 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float v = fmaf(acc[i], bsc, bsh);
+            if (a.res) v = v + rv[i];
+            if (a.relu) v = v > 0.0f ? v : 0.0f;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, moff[i], 0, 0);
+        }
+    }
+}
+
 size_t igemm_relayout_floats(int KH, int KW, int Cin, int Cout)
 {
     const int CoutP = (Cout + 31) / 32 * 32;
@@ -319,6 +457,22 @@ hipError_t launch_igemm(const float *x, int N, int H, int W, int Cin, const floa
     a.pad_t = th / 2;
     a.pad_l = tw / 2;
     a.M = (long)N * a.Ho * a.Wo;
+    if (KH == 3 && KW == 3 && Cin == 32 && stride == 1 && dil == 1 && !up2 && (long)H * W * (Cout > 32 ? Cout : 32) * 4 < (1L << 31)) {
+        HaloArgs q;
+        q.x = x; q.wt = wt; q.scale = scale; q.shift = shift; q.res = res; q.y = y;
+        q.N = N; q.H = H; q.W = W; q.Cout = Cout; q.CoutP = a.CoutP; q.relu = relu ? 1 : 0;
+        q.tiles_x = cdiv_i(W, HT_W); q.tiles_y = cdiv_i(H, HT_H); q.tiles_n = a.CoutP / 32;
+        const long ntiles = (long)N * q.tiles_x * q.tiles_y * q.tiles_n;
+        // persistent workgroups: two per CU (67 KB of LDS each), a multiple of the column-tile count
+        long grid = 512 / q.tiles_n * q.tiles_n;
+        if (grid > ntiles) grid = ntiles;
+        if (ntiles < (1L << 31)) {
+            ProfScope prof("k_conv3x3_c32", 2.0 * (double)a.M * 9 * Cin * Cout,
+                           4.0 * ((double)N * H * W * Cin + (double)a.M * Cout * (res ? 2.0 : 1.0) + 9.0 * Cin * Cout), s);
+            hipLaunchKernelGGL(k_conv3x3_c32, dim3((unsigned)grid), dim3(256), 0, s, q);
+            return hipGetLastError();
+        }
+    }
     // 32-bit byte offsets inside the kernel: every tensor of one launch must stay below 4 GiB (split the batch)
     if ((long)N * H * W * Cin * 4 >= (1L << 32) - 256 || a.M * Cout * 4 >= (1L << 32) - 256 || a.M >= (1L << 31) - 256)
         return hipErrorInvalidValue;

@@ -43,8 +43,8 @@ int ssal_icnet_forward_nhwc_u8(ssal_icnet *net, const uint8_t *x_dev, int n, int
 
 /* forward + softmax + acquisition measure + float64 per-image mean (active_learning.py:229-263), fused: the
  * full-resolution logits never reach HBM (the 4x bilinear conv6_interp is evaluated inside the score kernel).
- * Outputs as ssal_enet_score_nhwc: scores_dev [n] float64; optional label_dev / mask_dev uint8 [n,h,w],
- * conf_dev fp32 [n,h,w]. */
+ * Outputs as ssal_enet_score_nhwc: scores_dev [n] float64; optional label_dev / mask_dev uint8 [n,h,w] (4-byte
+ * aligned: four pixels leave per store), conf_dev fp32 [n,h,w] (16-byte aligned). */
 int ssal_icnet_score_nhwc(ssal_icnet *net, const float *x_dev, int n, int h, int w, int measure, float threshold,
                           double *scores_dev, uint8_t *label_dev, uint8_t *mask_dev, float *conf_dev, void *ws_dev,
                           int64_t ws_bytes, void *stream);
@@ -64,7 +64,9 @@ int ssal_icnet_endpoint_info(const ssal_icnet *net, const char *name, int n, int
  * y = [relu]( BN(conv2d(x, kernel HWIO, strides s, dilations d, "SAME")) [+ res] ), BN given as mean / variance /
  * gamma / beta (all NULL: no batch-norm; bias_dev optional).  upsample2x != 0 runs the conv on
  * tf.image.resize_bilinear(x, 2x) evaluated on the fly.  cin % 32 == 0 (matrix-core path) or cin in {1,3,4} with
- * a 3x3 / stride-2 / 32-channel kernel (first-layer path).  ws: ssal_conv_bn_workspace_bytes(). */
+ * a 3x3 / stride-2 / 32-channel kernel (first-layer path).  ws: ssal_conv_bn_workspace_bytes().  The kernel and the
+ * batch-norm vectors are host arrays: they are folded / re-laid-out and uploaded on every call (the call synchronises
+ * the stream once for that), which is what a per-operator test hook needs; the network handle does it once, at commit. */
 int64_t ssal_conv_bn_workspace_bytes(int kh, int kw, int cin, int cout);
 int ssal_conv_bn_act(const float *x_dev, int n, int h, int w, int cin, const float *kernel_host, int kh, int kw,
                      int cout, int stride, int dilation, const float *mean_host, const float *var_host,

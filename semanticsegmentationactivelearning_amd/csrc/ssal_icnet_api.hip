@@ -293,6 +293,8 @@ int score_any(ssal_icnet *net, const void *x_dev, bool u8, int n, int h, int w, 
     if (rc) return rc;
     if (measure < 0 || measure > 2) return fail(SSAL_ENOTIMPL, "Uncertainty function not implemented (measure=%d)", measure);
     if (!x_dev || !scores_dev || !ws_dev) return fail(SSAL_EINVAL, "NULL device pointer");
+    if (((uintptr_t)label_dev | (uintptr_t)mask_dev) & 3 || ((uintptr_t)conf_dev & 15))
+        return fail(SSAL_EINVAL, "label_dev / mask_dev must be 4-byte aligned and conf_dev 16-byte aligned");
     IcWorkspace W = carve(net, ws_dev, ws_bytes, n, h, w);
     if (!W.ok) return fail(SSAL_ENOMEM, "workspace too small: need %lld bytes, got %lld", (long long)W.bytes, (long long)ws_bytes);
     hipStream_t s = (hipStream_t)stream;
@@ -573,6 +575,8 @@ SSAL_API int ssal_upscore_logits_nhwc(const float *lq_dev, int n, int h, int w, 
     if (n <= 0 || h <= 0 || w <= 0) return fail(SSAL_EINVAL, "bad dims n=%d h=%d w=%d", n, h, w);
     if (classes < 2 || classes > 32) return fail(SSAL_EINVAL, "classes must be in [2,32] (got %d)", classes);
     if (!lq_dev || !scores_dev || !ws_dev) return fail(SSAL_EINVAL, "NULL device pointer");
+    if (((uintptr_t)label_dev | (uintptr_t)mask_dev) & 3 || ((uintptr_t)conf_dev & 15))
+        return fail(SSAL_EINVAL, "label_dev / mask_dev must be 4-byte aligned and conf_dev 16-byte aligned");
     if (ws_bytes < ssal_upscore_workspace_bytes(n, h, w)) return fail(SSAL_ENOMEM, "workspace too small");
     hipStream_t s = (hipStream_t)stream;
     Bump b(ws_dev, ws_bytes);

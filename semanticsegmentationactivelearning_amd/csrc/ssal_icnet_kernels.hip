@@ -413,6 +413,111 @@ __global__ __launch_bounds__(256) void k_conv3x3_c32(HaloArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 1x1 convolution on the 2x bilinearly up-sampled input, 128 channels -> at most 32 outputs (ICNET_SPEC
+// sub12_sum_interp -> conv6_cls): the generic UP2 loader fetches four source pixels and interpolates them for every
+// chunk of every output pixel -- 16 loads + ~150 VALU per chunk against 16 MFMAs.  Here a workgroup owns 8 x 16 output
+// pixels, stages the 5 x 9 SOURCE pixels they interpolate from ONCE in LDS (permuted-k rows, so the interpolated quad
+// of a lane half is already the MFMA operand sequence; the lerp is element-wise and commutes with the permutation) and
+// builds its A fragments from LDS: 4 ds_read_b128 + 12 lerps per 4 MFMAs.  Same arithmetic as k_igemm<1, true>.
+// ------------------------------------------------------------------------------------------------
+constexpr int CU_SH = HT_H / 2 + 1, CU_SW = HT_W / 2 + 1, CU_SP = CU_SH * CU_SW, CU_LDK = 128 + 4;  // 5 x 9 source pixels
+
+struct ClsUpArgs {
+    const float *x, *wt, *scale, *shift;
+    float *y;
+    int N, Hs, Ws, Cout, relu;  // Hs, Ws: source dims; the output is [N, 2Hs, 2Ws, Cout]
+    int tiles_x, tiles_y;
+};
+
+__global__ __launch_bounds__(256) void k_conv1x1_up2_c128(ClsUpArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float Ss[CU_SP * CU_LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[4 * 32 * IG_LDK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    int b = blockIdx.x;
+    const int tx = b % a.tiles_x; b /= a.tiles_x;
+    const int ty = b % a.tiles_y;
+    const int n = b / a.tiles_y;
+    const int oy0 = ty * HT_H, ox0 = tx * HT_W;  // even
+    const int sy0 = oy0 >> 1, sx0 = ox0 >> 1;
+    const int H = 2 * a.Hs, W = 2 * a.Ws;
+
+    // ---- stage source window + kernel: all loads first --------------------------------------------
+    const rsrc_t xrs = make_rsrc(a.x + (long)n * a.Hs * a.Ws * 128, (unsigned)(a.Hs * a.Ws * 512));
+    const rsrc_t wrs = make_rsrc(a.wt, 4u * 32u * 128u);
+    constexpr int SQ = CU_SP * 32, SIT = (SQ + 255) / 256;  // float4 quads of the window (32 per pixel)
+    float4 ss[SIT], sb[4];
+#pragma unroll
+    for (int it = 0; it < SIT; ++it) {
+        const int e = tid + 256 * it;
+        const int px = min(e >> 5, CU_SP - 1), q = e & 31;
+        const int sy = min(sy0 + px / CU_SW, a.Hs - 1), sx = min(sx0 + px % CU_SW, a.Ws - 1);  // clamped = y1 / x1 rule
+        ss[it] = bload4(xrs, e < SQ ? (unsigned)((sy * a.Ws + sx) * 512 + 16 * q) : IG_OOB, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) sb[t] = bload4(wrs, 16u * (unsigned)tid, (unsigned)t * 4096u);
+    const float bsc = a.scale[r], bsh = a.shift[r];
+#pragma unroll
+    for (int it = 0; it < SIT; ++it) {
+        const int e = tid + 256 * it;
+        if (e < SQ) {  // permuted-k row (igemm_kpos)
+            float *sp = Ss + (e >> 5) * CU_LDK + 8 * ((e & 31) >> 1) + 2 * (e & 1);
+            *reinterpret_cast<float2 *>(sp) = make_float2(ss[it].x, ss[it].z);
+            *reinterpret_cast<float2 *>(sp + 4) = make_float2(ss[it].y, ss[it].w);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        *reinterpret_cast<float4 *>(Bs + (t * 32 + (tid >> 3)) * IG_LDK + 4 * (tid & 7)) = sb[t];
+    __syncthreads();
+
+    // ---- this lane's output pixel and its four source pixels (tf.image.resize_bilinear, legacy mapping) ----
+    const int pr = 2 * wave + (r >> 4), pc = r & 15;
+    const float ly = (pr & 1) ? 0.5f : 0.0f, lx = (pc & 1) ? 0.5f : 0.0f;
+    const int y0 = pr >> 1, x0 = pc >> 1;  // window coordinates; the +1 neighbours were clamped while staging
+    const float *ptl = Ss + (y0 * CU_SW + x0) * CU_LDK + 4 * h;
+    const float *ptr_ = ptl + CU_LDK, *pbl = ptl + CU_SW * CU_LDK, *pbr = pbl + CU_LDK;
+    const float *Bb = Bs + r * IG_LDK + 4 * h;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    auto lerp4 = [&](const float4 &tl, const float4 &tr, const float4 &bl, const float4 &br) {
+        auto l1 = [&](float ctl, float ctr, float cbl, float cbr) {
+            const float top = ctl + (ctr - ctl) * lx;
+            const float bot = cbl + (cbr - cbl) * lx;
+            return top + (bot - top) * ly;
+        };
+        return make_float4(l1(tl.x, tr.x, bl.x, br.x), l1(tl.y, tr.y, bl.y, br.y), l1(tl.z, tr.z, bl.z, br.z),
+                           l1(tl.w, tr.w, bl.w, br.w));
+    };
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {  // 8-channel groups in ascending order: chunk g / 4, group g % 4
+        const float4 tl = *reinterpret_cast<const float4 *>(ptl + 8 * g), tr = *reinterpret_cast<const float4 *>(ptr_ + 8 * g);
+        const float4 bl = *reinterpret_cast<const float4 *>(pbl + 8 * g), br = *reinterpret_cast<const float4 *>(pbr + 8 * g);
+        const float4 bf = *reinterpret_cast<const float4 *>(Bb + (g >> 2) * 32 * IG_LDK + 8 * (g & 3));
+        const float4 af = lerp4(tl, tr, bl, br);
+        acc = mfma32(af.x, bf.x, acc);
+        acc = mfma32(af.y, bf.y, acc);
+        acc = mfma32(af.z, bf.z, acc);
+        acc = mfma32(af.w, bf.w, acc);
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------
+    const bool cok = r < a.Cout;
+    const rsrc_t yrs = make_rsrc(a.y + (long)n * H * W * a.Cout, (unsigned)(H * W * a.Cout * 4));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int m = (i & 3) + 8 * (i >> 2) + 4 * h;
+        const int oy = oy0 + 2 * wave + (m >> 4), ox = ox0 + (m & 15);
+        float v = fmaf(acc[i], bsc, bsh);
+        if (a.relu) v = v > 0.0f ? v : 0.0f;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs,
+                                              (cok && oy < H && ox < W) ? (unsigned)(((oy * W + ox) * a.Cout + r) * 4) : IG_OOB, 0, 0);
+    }
+}
+
 size_t igemm_relayout_floats(int KH, int KW, int Cin, int Cout)
 {
     const int CoutP = (Cout + 31) / 32 * 32;
@@ -457,6 +562,19 @@ hipError_t launch_igemm(const float *x, int N, int H, int W, int Cin, const floa
     a.pad_t = th / 2;
     a.pad_l = tw / 2;
     a.M = (long)N * a.Ho * a.Wo;
+    if (KH == 1 && KW == 1 && Cin == 128 && Cout <= 32 && stride == 1 && up2 && !res && (long)4 * H * W * Cout * 4 < (1L << 31)) {
+        ClsUpArgs q;
+        q.x = x; q.wt = wt; q.scale = scale; q.shift = shift; q.y = y;
+        q.N = N; q.Hs = H; q.Ws = W; q.Cout = Cout; q.relu = relu ? 1 : 0;
+        q.tiles_x = cdiv_i(2 * W, HT_W); q.tiles_y = cdiv_i(2 * H, HT_H);
+        const long grid = (long)N * q.tiles_x * q.tiles_y;
+        if (grid < (1L << 31)) {
+            ProfScope prof("k_conv1x1_up2_c128", 2.0 * (double)a.M * Cin * Cout,
+                           4.0 * ((double)N * H * W * Cin + (double)a.M * Cout + (double)Cin * Cout), s);
+            hipLaunchKernelGGL(k_conv1x1_up2_c128, dim3((unsigned)grid), dim3(256), 0, s, q);
+            return hipGetLastError();
+        }
+    }
     if (KH == 3 && KW == 3 && Cin == 32 && stride == 1 && dil == 1 && !up2 && (long)H * W * (Cout > 32 ? Cout : 32) * 4 < (1L << 31)) {
         HaloArgs q;
         q.x = x; q.wt = wt; q.scale = scale; q.shift = shift; q.res = res; q.y = y;

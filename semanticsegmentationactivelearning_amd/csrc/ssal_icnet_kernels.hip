@@ -975,8 +975,8 @@ __global__ __launch_bounds__(256) void k_upscore(const float *__restrict__ lq, i
                 float l[K];
 #pragma unroll
                 for (int k = 0; k < K; ++k) l[k] = top[k] + (bot[k] - top[k]) * ly;
-                int lab;
-                const float cf = pixel_score<K>(l, measure, inv_logK, lab);
+                int lab = 0;
+                const float cf = OUT ? pixel_score<K>(l, measure, inv_logK, lab) : pixel_score_only<K>(l, measure, inv_logK);
                 local += (double)cf;
                 if (OUT) {
                     lab4[dy] |= (unsigned)lab << (8 * dx);

@@ -48,6 +48,48 @@ __device__ __forceinline__ float pixel_score(const float (&l)[K], int measure, f
     return 1.0f / S;
 }
 
+// Score-only form (no label): the same arithmetic per measure, but only the quantities that measure needs -- the
+// class-argmax index and the running second-largest exponential of the generic form above cost more VALU work than
+// the softmax itself.  `measure` is wave-uniform, so the three bodies are three branches of one kernel.
+//   entropy   : m, S, T                                    (bit-identical to pixel_score: same ops, same order)
+//   margin    : (m1, m2) = the two largest logits (m2 == m1 on a tie), S;  e_(2) = exp(m2 - m1) is the very value the
+//               generic form finds as the largest exponential among the other classes
+//   confidence: m, S
+template <int K>
+__device__ __forceinline__ float pixel_score_only(const float (&l)[K], int measure, float inv_logK)
+{
+    if (measure == 1) {
+        float m1 = l[0], m2 = -__builtin_inff();
+#pragma unroll
+        for (int k = 1; k < K; ++k) {
+            m2 = fmaxf(m2, fminf(m1, l[k]));
+            m1 = fmaxf(m1, l[k]);
+        }
+        float S = 0.0f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) S += __expf(l[k] - m1);
+        return (1.0f - __expf(m2 - m1)) / S;
+    }
+    float m = l[0];
+#pragma unroll
+    for (int k = 1; k < K; ++k) m = fmaxf(m, l[k]);
+    float S = 0.0f, T = 0.0f;
+    if (measure == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float d = l[k] - m;
+            const float e = __expf(d);
+            S += e;
+            T = fmaf(e, fmaxf(d, -3.0e38f), T);
+        }
+        const float Hn = __logf(S) - T / S;
+        return 1.0f - Hn * inv_logK;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) S += __expf(l[k] - m);
+    return 1.0f / S;
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll

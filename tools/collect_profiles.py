@@ -8,7 +8,7 @@ for model in ("enet", "icnet"):
     fs = glob.glob(os.path.join(SRC, "prof_final_%s" % model, "runc", "*_kernel_stats.csv"))
     if fs:
         # keep the kernel rows (drop torch helper kernels' very long names by truncating the name column)
-        rows = open(fs[0]).read().splitlines()
+        rows = open(max(fs, key=os.path.getmtime)).read().splitlines()
         open(os.path.join(DST, "%s_%s_kernel_stats.csv" % (RND, model)), "w").write("\n".join(r[:400] for r in rows) + "\n")
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), model, RND])
 for src, dst in (("bench_enet_full.json", "%s_bench_enet_full_pool.json" % RND), ("bench_icnet.json", "%s_bench_icnet.json" % RND)):

@@ -8,7 +8,7 @@ from oracle import icnet_oracle as io
 
 d = sys.argv[1]
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-f = glob.glob(os.path.join(d, "runc", "*_kernel_trace.csv"))[0]
+f = max(glob.glob(os.path.join(d, "runc", "*_kernel_trace.csv")), key=os.path.getmtime)
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 ks = [(r["Kernel_Name"].split("(")[0].replace("void ssal::", "").replace("ssal::", ""),
        (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in rows]

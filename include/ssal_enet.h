@@ -197,7 +197,7 @@ int ssal_debug_set_knob(const char *name, int value);
 int ssal_debug_get_knobs(char *json_out, int64_t cap);
 
 /* measurement aid (tools/mem_probe.py): y = x for an [n,h,w,64] tensor with the access shape `mode`
- * (0 linear, 1 MFMA-fragment tile, 2 coalesced tile, 3/4 = 1/2 + halo-ring reads, 5-8 other tile shapes, 9 group by group, 10-13 linear with 16 / 16 / 4 / 2 float4 per thread, 14 = 10 in slab order); h % 8 == 0, w % 32 == 0;
+ * (0 linear, 1 MFMA-fragment tile, 2 coalesced tile, 3/4 = 1/2 + halo-ring reads, 5-8 other tile shapes, 9 group by group, 10-13 linear with 16 / 16 / 4 / 2 float4 per thread, 14 = 10 in slab order, 15-18 persistent workgroups that prefetch the next tile); h % 8 == 0, w % 32 == 0;
  * spin = shader clocks of ALU work between the loads and the stores. */
 int ssal_debug_copy_probe(int mode, const float *x_dev, float *y_dev, int n, int h, int w, int spin,
                           void *stream);

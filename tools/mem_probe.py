@@ -10,7 +10,10 @@ x = torch.randn(n, h, w, 64, device="cuda"); y = torch.empty_like(x); y2 = torch
 names = ["linear", "tile 8x32 frag", "tile 8x32 coalesced", "tile 8x32 frag+halo", "tile 8x32 coalesced+halo",
          "tile 4x64 frag", "tile 2x128 frag", "tile 1x256 frag", "tile 16x16 frag", "tile 8x32 frag, group by group",
          "linear, 16 float4/thread batch", "linear, 16 float4/thread loop", "linear, 4 float4/thread batch",
-         "linear, 2 float4/thread batch", "linear, 16 float4/thread batch, slab order"]
+         "linear, 2 float4/thread batch", "linear, 16 float4/thread batch, slab order",
+         "persistent 8x32 tiles, next tile prefetched, 768 WGs", "persistent 8x16 tiles, prefetched, 1024 WGs",
+         "persistent 8x32 tiles, prefetched, 512 WGs", "persistent 8x16 tiles, prefetched, 2048 WGs"]
+only = [int(a) for a in sys.argv[2:]]
 def run(mode, spin, reps=20, out=y):
     _lib.check(L.ssal_debug_copy_probe(mode, _lib.dev_ptr(x), _lib.dev_ptr(out), n, h, w, spin, _lib.stream_ptr()))
     torch.cuda.synchronize()
@@ -22,6 +25,8 @@ def run(mode, spin, reps=20, out=y):
     return e0.elapsed_time(e1) / reps * 1e3
 print("tensor [%d,%d,%d,64] fp32 = %.0f MB in + the same out" % (n, h, w, x.numel() * 4 / 1e6))
 for mode in range(len(names)):
+    if only and mode not in only:
+        continue
     y.zero_()
     us = run(mode, 0)
     assert torch.equal(x, y), names[mode]

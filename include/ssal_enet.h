@@ -173,7 +173,11 @@ int ssal_synth_frames_nhwc(uint64_t seed, int64_t first_frame, int count, int h,
 int ssal_synth_frames_nhwc_u8(uint64_t seed, int64_t first_frame, int count, int h, int w, int c,
                               uint8_t *out_dev, void *stream);
 
-/* Kernel-family switch for A/B measurements and cross-checks (no reference counterpart):
+/* The switches below (ssal_set_kernel_family, ssal_debug_set_knob, ssal_debug_set_trace, ssal_profile_*) are
+ * PROCESS-GLOBAL measurement aids, not part of the re-entrant per-handle / per-stream contract stated at the top of
+ * this header: set them from one host thread while no other thread is inside the library.
+ *
+ * Kernel-family switch for A/B measurements and cross-checks (no reference counterpart):
  * 1 = MFMA-fused bottleneck kernels on the shapes they support (default), 0 = generic kernels
  * everywhere.  Both families produce bit-identical results. */
 int ssal_set_kernel_family(int use_mfma);

@@ -266,3 +266,41 @@ def test_matches_golden_fixture(icnet19):
         report_diff(m + " mean vs golden", s.cpu().numpy(), g["mean_" + m], exact=False, atol=1e-6)
     report_diff("1/4-resolution logits vs golden", net.endpoint("conv6_cls").cpu().numpy(), g["logits_quarter"])
     report_diff("sub12_sum slice vs golden", net.endpoint("sub12_sum").cpu().numpy()[0, :4, :4, :], g["sub12_sum_slice"])
+
+
+def test_icnet_from_tfrecords_and_inference_path(icnet19, tmp_path):
+    """the callers on either side of the path take ICNet unchanged: TFRecords -> InputStage (uint8 frames, pinned
+    batches, side-stream copy) -> ICNet margin ranking; and inference.predict_labels / run_inference"""
+    import os
+    from PIL import Image
+    from test_input_cpu import write_pool
+    from semanticsegmentationactivelearning_amd import inference as inf
+    from semanticsegmentationactivelearning_amd.tensortools import InputStage, NumpyCapsule
+    net, P = icnet19
+    num, k = 6, 2
+    files = write_pool(str(tmp_path), num, 64, 64, with_label=False)
+    cap = NumpyCapsule(shuffle=True, seed=5)
+    cap.filenames, cap.indices = files, np.arange(num)
+    cap.labelled = np.zeros(num, dtype=bool)
+    stage = InputStage(input_shape=[64, 64], seed=6, image_dtype=np.uint8, pin_memory=True)
+    stage.add_dataset_from_placeholders("train", cap.filenames, cap.labelled, cap.indices, batch_size=4)
+    stage.init_iterator("train", None, cap.feed_dict)
+
+    def batches():
+        for image, label, mask, labelled, index in stage:
+            yield image, index
+
+    unlabelled = np.arange(num)
+    low, uc = al.rank_confidence(net, batches(), num, unlabelled, k, measure="margin", prefetch=2)
+    want = np.concatenate([ico.score_images(P, frames([i], 64, 64, 3), "margin")[0] for i in range(num)])
+    want_low, want_uc = orc.rank_lowest(want, unlabelled, k)
+    assert set(low.tolist()) == set(want_low.tolist())
+    report_diff("unlabelled_confidence", uc, want_uc, exact=False, atol=1e-6)
+    # inference.py path (reference inference.py:95-119)
+    x = frames([30, 31], 64, 96, 3)
+    want_logits = ico.icnet_forward(P, x)
+    pred = inf.predict_labels(net, dev(x))
+    report_diff("trainId map", pred.cpu().numpy(), want_logits.argmax(-1).astype(np.uint8))
+    paths = inf.run_inference(net, [(x, [b"a", "b"])], str(tmp_path / "out"))
+    assert [os.path.basename(p) for p in paths] == ["a.png", "b.png"]
+    assert (np.asarray(Image.open(paths[0])) == want_logits[0].argmax(-1)).all()

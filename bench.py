@@ -150,12 +150,27 @@ def main():
     dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # launched through torch.distributed.run: initialise the process group even for ONE rank, so that the single-GPU
+    # rehearsal of the launcher command exercises the RCCL branch (init with device_id, barriers, reductions)
+    use_dist = world > 1 or os.environ.get("TORCHELASTIC_RUN_ID") is not None
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "gloo":
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        # RCCL prints its banner (host name, library path) on the C-level stdout when the communicator comes up:
+        # stdout carries exactly ONE JSON line, so fd 1 points at stderr until the first collective has run
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "gloo":
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     knobs = _lib.get_knobs()
     if not knobs["defaults"] and not args.allow_nondefault_knobs:
@@ -214,7 +229,7 @@ def main():
     def merge_and_select(index, score):
         # ONE collective: every rank ran the same number of steps, so each pads its (index, score) shard locally
         # to steps * batch entries (a shard's last batch may be short) and all-gathers it
-        if world > 1:
+        if use_dist:
             index, score = al.pad_to_length(index, score, max(args.steps, args.warmup, 1) * bs)
         all_index, all_score = al.all_gather_scores(index, score)
         return al.finish_ranking(all_index.cpu().numpy(), all_score.cpu().numpy(), POOL,
@@ -227,19 +242,19 @@ def main():
     log("warm-up done")
 
     # ---- timed region: exactly --steps steps, barrier + synchronize on both sides -----------------
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     index, score, frames = run_steps(args.steps, 0 if args.scaling == "strong" else args.warmup)
     low, _ = merge_and_select(index, score)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     log("timed region: %d steps in %.3f s on this rank" % (args.steps, elapsed))
     t = torch.tensor([elapsed, float(frames)], dtype=torch.float64, device="cpu" if backend == "gloo" else dev)
-    if world > 1:
+    if use_dist:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -324,7 +339,7 @@ def main():
         # only meaningful when the whole pool was scored (default --steps 372 at N=1, or --scaling strong)
         result["top_k_checksum"] = int(np.sort(low).astype(np.int64).sum()) if int(total_frames) >= POOL else None
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -102,8 +102,15 @@ def all_gather_scores(local_index, local_score, group=None):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local_index, local_score
+    return _gather_pairs(local_index, local_score, group)
+
+
+def _gather_pairs(local_index, local_score, group=None):
+    """the collective itself (also what the single-rank RCCL smoke test drives): pack the index next to the score in a
+    float64 pair -> [per, 2], one ``all_gather_into_tensor``"""
+    import torch
+    import torch.distributed as dist
     world = dist.get_world_size(group)
-    # one collective: pack the index bits next to the score in a float64 pair -> [per, 2]
     packed = torch.stack([local_index.to(torch.float64), local_score.to(torch.float64)], dim=1).contiguous()
     home = packed.device
     if packed.is_cuda and dist.get_backend(group) == "gloo":

@@ -68,3 +68,35 @@ def test_two_ranks_one_gpu_real_scores_match_oracle(tmp_path):
     assert srt[K] - srt[K - 1] > 1e-5, "fixture must separate the k-th boundary"
     assert sorted(want_low.tolist()) == lows[0].tolist()
     assert np.abs(ucs[0] - want_u).max() <= 1e-6
+
+
+def _rccl_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    from semanticsegmentationactivelearning_amd import active_learning as al
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm (bench.py's call)
+    try:
+        idx = torch.arange(11, device=dev)
+        sc = torch.linspace(0.1, 0.9, 11, dtype=torch.float64, device=dev)
+        gi, gs = al._gather_pairs(idx, sc)  # all_gather_into_tensor on DEVICE tensors through RCCL
+        t = torch.tensor([3.5, 11.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the reductions bench.py issues after the timed region
+        dist.barrier()
+        torch.cuda.synchronize()
+        ok = torch.equal(gi, idx) and torch.equal(gs, sc) and t.tolist() == [3.5, 11.0] and gi.is_cuda
+        open(os.path.join(out_dir, "rccl_ok"), "w").write("1" if ok else "0")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_backend_executes_with_one_rank(tmp_path):
+    """One GPU cannot host two RCCL ranks, so this is NOT a multi-GPU test; it proves that the `nccl` branch
+    (init_process_group with device_id, all_gather_into_tensor / all_reduce / barrier on device tensors) loads RCCL and
+    executes on this machine -- the part the gloo rehearsals cannot reach."""
+    mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert open(tmp_path / "rccl_ok").read() == "1"

@@ -29,6 +29,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# the host driver of the GPU pool only supports dmabuf IPC: RCCL / device-tensor sharing across the ranks of one node
+# needs this before the HIP runtime comes up (it is exported on the pool already; kept here for any other launcher)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 POOL = 2975          # Cityscapes train split size (BASELINE.json configs[1])
 TOP_K = 128          # BASELINE.json configs[2]

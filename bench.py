@@ -340,7 +340,9 @@ def main():
 
     if rank == 0:
         # only meaningful when the whole pool was scored (default --steps 372 at N=1, or --scaling strong)
-        result["top_k_checksum"] = int(np.sort(low).astype(np.int64).sum()) if int(total_frames) >= POOL else None
+        # (and no resident batch was scored twice: --resident-gib did not make the batch list wrap around)
+        whole_pool = int(total_frames) >= POOL and n_resident >= min(args.steps, n_batches_shard)
+        result["top_k_checksum"] = int(np.sort(low).astype(np.int64).sum()) if whole_pool else None
         print(json.dumps(result), flush=True)
     if use_dist:
         dist.barrier()

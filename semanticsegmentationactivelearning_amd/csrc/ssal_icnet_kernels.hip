@@ -562,7 +562,8 @@ hipError_t launch_igemm(const float *x, int N, int H, int W, int Cin, const floa
     a.pad_t = th / 2;
     a.pad_l = tw / 2;
     a.M = (long)N * a.Ho * a.Wo;
-    if (KH == 1 && KW == 1 && Cin == 128 && Cout <= 32 && stride == 1 && up2 && !res && (long)4 * H * W * Cout * 4 < (1L << 31)) {
+    if (KH == 1 && KW == 1 && Cin == 128 && Cout <= 32 && stride == 1 && up2 && !res &&
+        (long)4 * H * W * Cout * 4 < (1L << 31) && (long)H * W * 512 < (1L << 31)) {  // 32-bit offsets inside one image
         ClsUpArgs q;
         q.x = x; q.wt = wt; q.scale = scale; q.shift = shift; q.y = y;
         q.N = N; q.Hs = H; q.Ws = W; q.Cout = Cout; q.relu = relu ? 1 : 0;

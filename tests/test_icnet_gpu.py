@@ -304,3 +304,52 @@ def test_icnet_from_tfrecords_and_inference_path(icnet19, tmp_path):
     paths = inf.run_inference(net, [(x, [b"a", "b"])], str(tmp_path / "out"))
     assert [os.path.basename(p) for p in paths] == ["a.png", "b.png"]
     assert (np.asarray(Image.open(paths[0])) == want_logits[0].argmax(-1)).all()
+
+
+def test_conv_bn_act_random_shapes_bit_exact():
+    """seeded sweep over the fused convolution's argument space (kernel size, channel counts incl. non-multiples of 32
+    on the output side, stride, dilation, ragged spatial sizes, shortcut add, ReLU, on-the-fly 2x interpolation): every
+    case bit-exact against the C oracle.  Covers the dispatch between k_igemm<1|2|4>, k_conv3x3_c32 and
+    k_conv1x1_up2_c128."""
+    rng = np.random.default_rng(20260)
+    cases = 0
+    for _ in range(48):
+        kh = int(rng.choice([1, 3]))
+        cin = int(rng.choice([32, 32, 64, 96, 128, 160]))
+        cout = int(rng.choice([1, 7, 19, 32, 33, 64, 96, 100, 128, 130, 256]))
+        stride = int(rng.choice([1, 1, 2]))
+        dil = int(rng.choice([1, 1, 2, 3, 4])) if kh == 3 else 1
+        n, h, w = int(rng.integers(1, 4)), int(rng.integers(1, 29)), int(rng.integers(1, 37))
+        up2 = bool(rng.integers(0, 4) == 0) and stride == 1
+        res = bool(rng.integers(0, 2))
+        relu = bool(rng.integers(0, 2))
+        x = rng.normal(size=(n, h, w, cin)).astype(np.float32)
+        k = (rng.normal(size=(kh, kh, cin, cout)) / np.sqrt(kh * kh * cin)).astype(np.float32)
+        bn = _bn(rng, cout)
+        hh, ww = (2 * h, 2 * w) if up2 else (h, w)
+        oh, ow = -(-hh // stride), -(-ww // stride)
+        r = rng.normal(size=(n, oh, ow, cout)).astype(np.float32) if res else None
+        want = _oracle_conv(x, k, stride, dil, bn, None, r, relu, up2)
+        got = cops.conv_bn_act(dev(x), k, stride, dil, bn=bn, residual=None if r is None else dev(r), relu=relu,
+                               upsample2x=up2)
+        report_diff("case k%d cin%d cout%d s%d d%d n%d %dx%d up2=%s res=%s" % (kh, cin, cout, stride, dil, n, h, w, up2, res),
+                    got.cpu().numpy(), want)
+        cases += 1
+    assert cases == 48
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_icnet_random_sizes_and_batches(icnet19, seed):
+    """whole network at random multiples of 32 (non-square, tiny and mid sizes) and batch sizes: logits bit-exact"""
+    net, P = icnet19
+    rng = np.random.default_rng(seed)
+    for _ in range(3):
+        n = int(rng.integers(1, 4))
+        h, w = 32 * int(rng.integers(1, 6)), 32 * int(rng.integers(1, 8))
+        x = frames(list(range(60, 60 + n)), h, w, 3)
+        want = ico.icnet_forward(P, x)
+        got = net(dev(x), training=False).cpu().numpy()
+        report_diff("ICNet %dx%dx%d" % (n, h, w), got, want)
+        s = net.score(dev(x), "margin")
+        wm = orc.score_logits(want, "margin")[0]
+        report_diff("margin mean %dx%dx%d" % (n, h, w), s.cpu().numpy(), wm, exact=False, atol=1e-6)

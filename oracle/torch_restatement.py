@@ -121,8 +121,16 @@ _STAGE23 = [(1, 1, False), (2, 2, False), (3, 1, True), (4, 4, False), (5, 1, Fa
 
 
 @torch.no_grad()
-def enet_forward(P, x_nhwc, endpoints=None):
-    """numpy NHWC in -> numpy NHWC logits"""
+def enet_forward(P, x_nhwc, endpoints=None, pooling_indices=None):
+    """numpy NHWC in -> numpy NHWC logits.
+
+    pooling_indices = {"argmax1": [N,H/4,W/4,64] int64, "argmax2": [N,H/8,W/8,128]} (reference convention) makes the two
+    unpool layers scatter to THOSE positions instead of this restatement's own argmax.  Two fp32 evaluations of the same
+    network round differently, so a pooling window whose two largest values are within an ulp or two can elect a different
+    winner; the unpool layer then writes the (practically equal) value to a different pixel and the logits around it
+    differ by O(1) -- a property of max-pool-with-argmax + unpool under ANY change of summation order (it would show
+    against TensorFlow's own kernels just the same), not an error of either side.  Comparing 'given the same winners'
+    separates that effect from real numerical disagreement."""
     ep = endpoints if endpoints is not None else {}
 
     def rec(name, t):
@@ -134,11 +142,15 @@ def enet_forward(P, x_nhwc, endpoints=None):
     y, a1 = bottleneck_down(P, "Bottleneck1_0", y)
     rec("Bottleneck1_0", y)
     ep["argmax1"] = a1.permute(0, 2, 3, 1).contiguous().numpy()
+    if pooling_indices is not None:
+        a1 = torch.from_numpy(np.ascontiguousarray(pooling_indices["argmax1"]).astype(np.int64)).permute(0, 3, 1, 2)
     for i in range(1, 5):
         y = rec("Bottleneck1_%d" % i, bottleneck(P, "Bottleneck1_%d" % i, y))
     y, a2 = bottleneck_down(P, "Bottleneck2_0", y)
     rec("Bottleneck2_0", y)
     ep["argmax2"] = a2.permute(0, 2, 3, 1).contiguous().numpy()
+    if pooling_indices is not None:
+        a2 = torch.from_numpy(np.ascontiguousarray(pooling_indices["argmax2"]).astype(np.int64)).permute(0, 3, 1, 2)
     for stage in (2, 3):
         for i, dil, asym in _STAGE23:
             nm = "Bottleneck%d_%d" % (stage, i)

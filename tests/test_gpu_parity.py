@@ -349,7 +349,16 @@ def _check_forward(net, P, x, tag):
     report_diff(tag + " bottleneck4_2", b4_2.cpu().numpy(), ep["Bottleneck4_2"])
     report_diff(tag + " bottleneck5_1", b5_1.cpu().numpy(), ep["Bottleneck5_1"])
     report_diff(tag + " logits vs C oracle (bit-exact)", got, want)
-    wb = tr.enet_forward(P, x)
+    wep = {}
+    wb = tr.enet_forward(P, x, wep)
+    # two fp32 evaluations may elect different winners in a pooling window whose two largest values are an ulp apart
+    # (1 window of 524 288 on the 512x1024 frame of test_forward_reference_conf_frame_sizes); the unpool layer then moves
+    # the value by a pixel and the logits around it differ by O(1).  Such windows must be rare, and given the SAME
+    # winners the two restatements must agree within the tolerance everywhere.
+    flips = sum(int((wep[a] != ep[a]).sum()) for a in ("argmax1", "argmax2"))
+    if flips:
+        assert flips <= max(1, int(1e-5 * (ep["argmax1"].size + ep["argmax2"].size))), flips
+        wb = tr.enet_forward(P, x, pooling_indices={a: ep[a] for a in ("argmax1", "argmax2")})
     report_diff(tag + " logits vs torch restatement", got, wb, exact=False, atol=TOL)
     return got, want
 
@@ -662,6 +671,21 @@ def test_forward_c5_medium_rgb_nir(enet_c4k6):
     scores, extra = net.score(dev(x), "entropy", return_label=True)
     report_diff("C5 label", extra["label"].cpu().numpy(), want_label)
     report_diff("C5 mean", scores.cpu().numpy(), want_mean, exact=False, atol=1e-6)
+
+
+def test_forward_reference_conf_frame_sizes(enet_c3k19, enet_c4k6):
+    """The frame sizes the reference's own parameter files configure (conf/freiburg_forest.json:33-34: 432x648, whose
+    stage-2/3 maps are 54x81 -- odd width, partial tiles in every kernel; conf/enet_cityscapes_*.json:33-34: 512x1024):
+    forward + entropy score + label, RGB+NIR / 6 classes for Freiburg (BASELINE config C5), 3 channels / 19 classes for
+    Cityscapes."""
+    for (net, P), h, w, c, tag in ((enet_c4k6, 432, 648, 4, "freiburg-432x648"), (enet_c3k19, 512, 1024, 3, "cityscapes-512x1024")):
+        x = frames([7], h, w, c)
+        got, want = _check_forward(net, P, x, tag)
+        want_mean, want_conf, want_label = orc.score_logits(want, "entropy")
+        scores, extra = net.score(dev(x), "entropy", return_label=True, return_confidence=True)
+        report_diff(tag + " label", extra["label"].cpu().numpy(), want_label)
+        report_diff(tag + " conf", extra["confidence"].cpu().numpy(), want_conf, exact=False, atol=TOL)
+        report_diff(tag + " mean", scores.cpu().numpy(), want_mean, exact=False, atol=1e-6)
 
 
 # ---- round 2: parity hardening -------------------------------------------------------------------

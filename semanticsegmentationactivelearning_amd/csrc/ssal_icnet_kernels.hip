@@ -96,28 +96,55 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
     const unsigned rowb = (unsigned)(Ws * a.Cin * 4), pixb = (unsigned)(a.Cin * 4);
 
     float4 ra[4], rb[NT];
-    auto gload = [&](int t) {
-        const int tap = t / cpt, cc = t - tap * cpt;
-        const int kh = tap / a.KW, kw = tap - kh * a.KW;
-        const unsigned cofs = 128u * cc;
+    // Loader state: the NEXT chunk to request is (tap = (ld_kh, ld_kw), channel chunk ld_cc).  The per-row byte offsets
+    // (and SAME-padding validity) depend on the tap only: they are computed when a new tap starts and kept in registers;
+    // within a tap a chunk only adds the wave-uniform 128 * ld_cc, which rides in the instruction's scalar offset
+    // (excluded from the range check, so an out-of-range row offset stays out of range).  A 1x1 convolution computes its
+    // offsets once; a 3x3 one on 256 channels once per 8 chunks.
+    constexpr int NOFF = UP2 ? 16 : 4;
+    unsigned aoff[NOFF];
+    float lyv[4], lxv[4];  // UP2: the two interpolation weights of each row (0 or 0.5)
+    int ld_cc = 0, ld_kh = 0, ld_kw = 0;
+    unsigned ld_wofs = (unsigned)n0 * 128u;  // wave-uniform byte offset of the kernel rows of the next chunk
+    auto tap_offsets = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int iy = iyb[i] + kh * a.dil, ix = ixb[i] + kw * a.dil;
+            const int iy = iyb[i] + ld_kh * a.dil, ix = ixb[i] + ld_kw * a.dil;
             const bool ok = mv[i] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
             if (!UP2) {
-                const unsigned off = nbase[i] + (unsigned)iy * rowb + (unsigned)ix * pixb + cofs;
-                ra[i] = bload4(xrs, ok ? off : IG_OOB, 0);
+                aoff[i] = ok ? nbase[i] + (unsigned)iy * rowb + (unsigned)ix * pixb : IG_OOB;
             } else {
                 // tf.image.resize_bilinear(src, 2x), legacy mapping src = dst * 0.5 (ICNET_SPEC "bilinear resize");
                 // out-of-image taps read four zeros and interpolate to an exact zero
                 const int y0 = iy >> 1, x0 = ix >> 1;
                 const int y1 = min(y0 + 1, Hs - 1), x1 = min(x0 + 1, Ws - 1);
-                const float ly = (iy & 1) ? 0.5f : 0.0f, lx = (ix & 1) ? 0.5f : 0.0f;
-                const unsigned b0 = nbase[i] + cofs;
-                const float4 tl = bload4(xrs, ok ? b0 + (unsigned)y0 * rowb + (unsigned)x0 * pixb : IG_OOB, 0);
-                const float4 tr = bload4(xrs, ok ? b0 + (unsigned)y0 * rowb + (unsigned)x1 * pixb : IG_OOB, 0);
-                const float4 bl = bload4(xrs, ok ? b0 + (unsigned)y1 * rowb + (unsigned)x0 * pixb : IG_OOB, 0);
-                const float4 br = bload4(xrs, ok ? b0 + (unsigned)y1 * rowb + (unsigned)x1 * pixb : IG_OOB, 0);
+                lyv[i] = (iy & 1) ? 0.5f : 0.0f;
+                lxv[i] = (ix & 1) ? 0.5f : 0.0f;
+                const unsigned b0 = nbase[i];
+                aoff[4 * i + 0] = ok ? b0 + (unsigned)y0 * rowb + (unsigned)x0 * pixb : IG_OOB;
+                aoff[4 * i + 1] = ok ? b0 + (unsigned)y0 * rowb + (unsigned)x1 * pixb : IG_OOB;
+                aoff[4 * i + 2] = ok ? b0 + (unsigned)y1 * rowb + (unsigned)x0 * pixb : IG_OOB;
+                aoff[4 * i + 3] = ok ? b0 + (unsigned)y1 * rowb + (unsigned)x1 * pixb : IG_OOB;
+            }
+        }
+    };
+    // live = false (wave-uniform; the call past the last chunk): every offset is out of range, the loads return zeros and
+    // nothing reads them.  Keeping the call unconditional keeps the loaded registers out of a loop-carried PHI: with
+    // `if (more) gload()` the compiler copies them right behind the loads -- i.e. waits for them BEFORE the MFMAs of the
+    // current chunk instead of after.
+    auto gload = [&](bool live) {
+        if (live && ld_cc == 0) tap_offsets();  // wave-uniform
+        const unsigned cofs = 128u * (unsigned)ld_cc;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (!UP2) {
+                ra[i] = bload4(xrs, live ? aoff[i] : IG_OOB, cofs);
+            } else {
+                const float4 tl = bload4(xrs, live ? aoff[4 * i + 0] : IG_OOB, cofs);
+                const float4 tr = bload4(xrs, live ? aoff[4 * i + 1] : IG_OOB, cofs);
+                const float4 bl = bload4(xrs, live ? aoff[4 * i + 2] : IG_OOB, cofs);
+                const float4 br = bload4(xrs, live ? aoff[4 * i + 3] : IG_OOB, cofs);
+                const float lx = lxv[i], ly = lyv[i];
                 auto lerp2 = [&](float ctl, float ctr, float cbl, float cbr) {
                     const float top = ctl + (ctr - ctl) * lx;
                     const float bot = cbl + (cbr - cbl) * lx;
@@ -127,9 +154,13 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
                                     lerp2(tl.z, tr.z, bl.z, br.z), lerp2(tl.w, tr.w, bl.w, br.w));
             }
         }
-        const unsigned wofs = (unsigned)(t * a.CoutP + n0) * 128u;  // wave-uniform
 #pragma unroll
-        for (int j = 0; j < NT; ++j) rb[j] = bload4(wrs, 16u * (unsigned)(tid + 256 * j), wofs);
+        for (int j = 0; j < NT; ++j) rb[j] = bload4(wrs, live ? 16u * (unsigned)(tid + 256 * j) : IG_OOB, ld_wofs);
+        ld_wofs += (unsigned)a.CoutP * 128u;
+        if (++ld_cc == cpt) {
+            ld_cc = 0;
+            if (++ld_kw == a.KW) { ld_kw = 0; ++ld_kh; }
+        }
     };
     auto lds_write = [&](int buf) {
         float *As = smem + buf * (BM + BN) * LDK;
@@ -166,7 +197,7 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
 #else
 #define TR_MARK(acc_)  do { } while (0)
 #endif
-    gload(0);
+    gload(true);
     lds_write(0);
     __syncthreads();
 #ifdef SSAL_PHASE_TRACE
@@ -176,11 +207,15 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
     for (int t = 0; t < nchunks; ++t) {
         const bool more = t + 1 < nchunks;
 #ifdef SSAL_MEASURE
-        if (more && !(a.ablate & 2)) gload(t + 1);
+        gload(more && !(a.ablate & 2));
 #else
-        if (more) gload(t + 1);
+        if (NT >= 2) gload(more);     // measured: -3 % (NT = 4), -4 % (NT = 2); NT = 1 (natural-order A rows, no re-pairing
+        else if (more) gload(true);   // copies) is 4 % faster with the plain conditional form
 #endif
         TR_MARK(tr_gl);
+        // the loads of chunk t+1 stay in flight across the matrix section: nothing that consumes them (the register
+        // re-pairing of the permuted LDS writes, the 2x interpolation) may be scheduled above this chunk's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
         const float *As = smem + (t & 1) * (BM + BN) * LDK + (32 * wave + r) * LDK + 4 * h;
         const float *Bs = smem + (t & 1) * (BM + BN) * LDK + BM * LDK + r * LDK + 4 * h;
         // fragments of 8-k group g+1 are requested before the 4*NT MFMAs of group g: the LDS latency hides behind them
@@ -216,6 +251,7 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
             }
         }
         TR_MARK(tr_mm);
+        __builtin_amdgcn_sched_barrier(0);
 #ifdef SSAL_PHASE_TRACE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         TR_MARK(tr_vm);

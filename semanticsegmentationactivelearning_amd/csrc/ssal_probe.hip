@@ -77,11 +77,18 @@ __global__ __launch_bounds__(256) void k_probe_tile_seq(const float *x, float *y
     }
 }
 
-template <bool FRAG, bool HALO, int TH = 8, int TW = 32>
+// STAG > 0 (modes 19-21): every second first-round workgroup of a CU starts STAG cycles late, so that half of the resident
+// workgroups store while the other half load (are the chip-wide read and write bursts of lock-stepped workgroups what
+// keeps a tile-organised kernel below a linear copy?)
+template <bool FRAG, bool HALO, int TH = 8, int TW = 32, int STAG = 0>
 __global__ __launch_bounds__(256) void k_probe_tile(const float *x, float *y, int H, int W, int spin)
 {
     constexpr int C = 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (STAG > 0 && blockIdx.x < 1024 && ((blockIdx.x >> 8) & 1)) {
+        const long t0 = __builtin_amdgcn_s_memtime();
+        while ((long)__builtin_amdgcn_s_memtime() - t0 < STAG) __builtin_amdgcn_s_sleep(8);
+    }
     const int i16 = lane & 15, g = lane >> 4;
     const int tiles_x = W / TW, tiles_y = H / TH;
     int b = blockIdx.x;
@@ -201,7 +208,7 @@ hipError_t launch_copy_probe(int mode, const float *x, float *y, int N, int H, i
     const long n = (long)N * H * W * 64;
     static const char *names[] = {"probe linear", "probe tile frag", "probe tile coalesced", "probe tile frag+halo",
                                   "probe tile coalesced+halo"};
-    if (mode < 0 || mode > 18) return hipErrorInvalidValue;
+    if (mode < 0 || mode > 21) return hipErrorInvalidValue;
     ProfScope prof(mode <= 4 ? names[mode] : "probe tile shape", 0.0, 8.0 * n, s);
     const unsigned tiles = (unsigned)((long)N * (H / 8) * (W / 32));
     switch (mode) {
@@ -229,6 +236,9 @@ hipError_t launch_copy_probe(int mode, const float *x, float *y, int N, int H, i
     case 16: hipLaunchKernelGGL((k_probe_tile_persistent<16>), dim3(1024), dim3(256), 0, s, x, y, N, H, W, spin); break;
     case 17: hipLaunchKernelGGL((k_probe_tile_persistent<32>), dim3(512), dim3(256), 0, s, x, y, N, H, W, spin); break;
     case 18: hipLaunchKernelGGL((k_probe_tile_persistent<16>), dim3(2048), dim3(256), 0, s, x, y, N, H, W, spin); break;
+    case 19: hipLaunchKernelGGL((k_probe_tile<true, false, 8, 32, 12000>), dim3(tiles), dim3(256), 0, s, x, y, H, W, spin); break;
+    case 20: hipLaunchKernelGGL((k_probe_tile<true, false, 8, 32, 25000>), dim3(tiles), dim3(256), 0, s, x, y, H, W, spin); break;
+    case 21: hipLaunchKernelGGL((k_probe_tile<true, false, 8, 32, 50000>), dim3(tiles), dim3(256), 0, s, x, y, H, W, spin); break;
     case 13: hipLaunchKernelGGL((k_probe_linear_u<2, true>), dim3((unsigned)((n / 4 + 511) / 512)), dim3(256), 0, s,
                                 (const float4 *)x, (float4 *)y, n / 4); break;
     }

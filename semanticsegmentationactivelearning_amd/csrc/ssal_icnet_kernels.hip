@@ -55,6 +55,12 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
     // permuted while it is written to LDS when that pays: two 8-byte LDS writes per quad instead of one 16-byte
     // write, against 2 register swaps per fragment read -- a win when the fragment feeds several column tiles.
     constexpr bool A_PERMUTED = NT >= 2;
+#ifdef SSAL_MEASURE
+    constexpr bool MIDWRITE = false;  // the phase trace / phase ablation times the write phase on its own
+#else
+    constexpr bool MIDWRITE = NT >= 2;  // NT = 1: 16 MFMAs per chunk are over before the loads are back
+#endif
+    constexpr int WG_A = NT >= 4 ? 1 : 2, WG_B = WG_A + 1;  // 8-k groups after which the A rows / the kernel rows are written
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
     const int nchunks = a.KH * a.KW * cpt;
     const unsigned rowb = (unsigned)(Ws * a.Cin * 4), pixb = (unsigned)(a.Cin * 4);
 
-    float4 ra[4], rb[NT];
+    float4 rb[NT];
     // Loader state: the NEXT chunk to request is (tap = (ld_kh, ld_kw), channel chunk ld_cc).  The per-row byte offsets
     // (and SAME-padding validity) depend on the tap only: they are computed when a new tap starts and kept in registers;
     // within a tap a chunk only adds the wave-uniform 128 * ld_cc, which rides in the instruction's scalar offset
@@ -103,6 +109,7 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
     // offsets once; a 3x3 one on 256 channels once per 8 chunks.
     constexpr int NOFF = UP2 ? 16 : 4;
     unsigned aoff[NOFF];
+    float4 rq[NOFF];  // the loaded quads of the next chunk (UP2: the four neighbours tl, tr, bl, br of each row)
     float lyv[4], lxv[4];  // UP2: the two interpolation weights of each row (0 or 0.5)
     int ld_cc = 0, ld_kh = 0, ld_kw = 0;
     unsigned ld_wofs = (unsigned)n0 * 128u;  // wave-uniform byte offset of the kernel rows of the next chunk
@@ -136,14 +143,24 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
         if (live && ld_cc == 0) tap_offsets();  // wave-uniform
         const unsigned cofs = 128u * (unsigned)ld_cc;
 #pragma unroll
+        for (int q = 0; q < NOFF; ++q) rq[q] = bload4(xrs, live ? aoff[q] : IG_OOB, cofs);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) rb[j] = bload4(wrs, live ? 16u * (unsigned)(tid + 256 * j) : IG_OOB, ld_wofs);
+        ld_wofs += (unsigned)a.CoutP * 128u;
+        if (++ld_cc == cpt) {
+            ld_cc = 0;
+            if (++ld_kw == a.KW) { ld_kw = 0; ++ld_kh; }
+        }
+    };
+    auto lds_write_a = [&](int buf) {
+        float *As = smem + buf * (BM + BN) * LDK;
+        float4 ra[4];
+#pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (!UP2) {
-                ra[i] = bload4(xrs, live ? aoff[i] : IG_OOB, cofs);
-            } else {
-                const float4 tl = bload4(xrs, live ? aoff[4 * i + 0] : IG_OOB, cofs);
-                const float4 tr = bload4(xrs, live ? aoff[4 * i + 1] : IG_OOB, cofs);
-                const float4 bl = bload4(xrs, live ? aoff[4 * i + 2] : IG_OOB, cofs);
-                const float4 br = bload4(xrs, live ? aoff[4 * i + 3] : IG_OOB, cofs);
+                ra[i] = rq[i];
+            } else {  // the interpolation happens here, i.e. after the loads have had the matrix section to land
+                const float4 tl = rq[4 * i], tr = rq[4 * i + 1], bl = rq[4 * i + 2], br = rq[4 * i + 3];
                 const float lx = lxv[i], ly = lyv[i];
                 auto lerp2 = [&](float ctl, float ctr, float cbl, float cbr) {
                     const float top = ctl + (ctr - ctl) * lx;
@@ -154,17 +171,6 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
                                     lerp2(tl.z, tr.z, bl.z, br.z), lerp2(tl.w, tr.w, bl.w, br.w));
             }
         }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) rb[j] = bload4(wrs, live ? 16u * (unsigned)(tid + 256 * j) : IG_OOB, ld_wofs);
-        ld_wofs += (unsigned)a.CoutP * 128u;
-        if (++ld_cc == cpt) {
-            ld_cc = 0;
-            if (++ld_kw == a.KW) { ld_kw = 0; ++ld_kh; }
-        }
-    };
-    auto lds_write = [&](int buf) {
-        float *As = smem + buf * (BM + BN) * LDK;
-        float *Bs = As + BM * LDK;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (A_PERMUTED) {
@@ -177,12 +183,16 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
                 *reinterpret_cast<float4 *>(As + ((tid >> 3) + 32 * i) * LDK + 4 * col4) = ra[i];
             }
         }
+    };
+    auto lds_write_b = [&](int buf) {
+        float *Bs = smem + buf * (BM + BN) * LDK + BM * LDK;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int idx = tid + 256 * j;
             *reinterpret_cast<float4 *>(Bs + (idx >> 3) * LDK + 4 * (idx & 7)) = rb[j];
         }
     };
+    auto lds_write = [&](int buf) { lds_write_a(buf); lds_write_b(buf); };
 
     f32x16 acc[NT];
 #pragma unroll
@@ -249,6 +259,20 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
                 acc[nt] = mfma32(af[c].z, bf[c][nt].z, acc[nt]);
                 acc[nt] = mfma32(af[c].w, bf[c][nt].w, acc[nt]);
             }
+            // Chunk t+1 goes to the other LDS buffer (free since the barrier that ended chunk t-1) from INSIDE the matrix
+            // section: its loads have had half of the section to land, the re-pairing copies / the interpolation and the
+            // LDS write latency hide behind the remaining MFMAs, and nothing but the barrier is left after the last one.
+            // (NT >= 2 writes unconditionally: past the last chunk the registers hold zeros and the buffer is dead.)
+            if (MIDWRITE && g == WG_A) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (NT >= 2 || more) lds_write_a((t + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (MIDWRITE && g == WG_B) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (NT >= 2 || more) lds_write_b((t + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         TR_MARK(tr_mm);
         __builtin_amdgcn_sched_barrier(0);
@@ -256,11 +280,13 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         TR_MARK(tr_vm);
 #endif
+        if (!MIDWRITE) {
 #ifdef SSAL_MEASURE
-        if (more && !(a.ablate & 4)) lds_write((t + 1) & 1);
+            if (more && !(a.ablate & 4)) lds_write((t + 1) & 1);
 #else
-        if (more) lds_write((t + 1) & 1);
+            if (more) lds_write((t + 1) & 1);
 #endif
+        }
         TR_MARK(tr_wr);
         __syncthreads();
         TR_MARK(tr_bar);

@@ -216,6 +216,16 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
 #endif
     for (int t = 0; t < nchunks; ++t) {
         const bool more = t + 1 < nchunks;
+        // first fragments of this chunk: requested BEFORE the address arithmetic of the next chunk's loads, which hides
+        // their LDS latency
+        const float *As = smem + (t & 1) * (BM + BN) * LDK + (32 * wave + r) * LDK + 4 * h;
+        const float *Bs = smem + (t & 1) * (BM + BN) * LDK + BM * LDK + r * LDK + 4 * h;
+        // fragments of 8-k group g+1 are requested before the 4*NT MFMAs of group g: the LDS latency hides behind them
+        float4 af[2], bf[2][NT];
+        af[0] = *reinterpret_cast<const float4 *>(As);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bf[0][nt] = *reinterpret_cast<const float4 *>(Bs + 32 * nt * LDK);
+        __builtin_amdgcn_sched_barrier(0);
 #ifdef SSAL_MEASURE
         gload(more && !(a.ablate & 2));
 #else
@@ -226,13 +236,6 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
         // the loads of chunk t+1 stay in flight across the matrix section: nothing that consumes them (the register
         // re-pairing of the permuted LDS writes, the 2x interpolation) may be scheduled above this chunk's MFMAs
         __builtin_amdgcn_sched_barrier(0);
-        const float *As = smem + (t & 1) * (BM + BN) * LDK + (32 * wave + r) * LDK + 4 * h;
-        const float *Bs = smem + (t & 1) * (BM + BN) * LDK + BM * LDK + r * LDK + 4 * h;
-        // fragments of 8-k group g+1 are requested before the 4*NT MFMAs of group g: the LDS latency hides behind them
-        float4 af[2], bf[2][NT];
-        af[0] = *reinterpret_cast<const float4 *>(As);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bf[0][nt] = *reinterpret_cast<const float4 *>(Bs + 32 * nt * LDK);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
 #ifdef SSAL_MEASURE

@@ -386,7 +386,11 @@ __global__ __launch_bounds__(256) void k_conv3x3_c32(HaloArgs a)
         ty0 = (q % a.tiles_y) * HT_H;
         n = q / a.tiles_y;
     };
-    auto load_window = [&](int t) {  // unconditional buffer loads; outside the image = out-of-range offset = zeros
+    // unconditional buffer loads; outside the image = out-of-range offset = zeros.  live = false (wave-uniform; the call
+    // after the last tile): every offset out of range.  The call itself must stay unconditional: under `if (next tile)`
+    // the loaded registers become loop-carried PHIs whose copies -- and the wait for the loads -- the compiler places
+    // right behind the loads, i.e. BEFORE the K loop they are meant to overlap.
+    auto load_window = [&](int t, bool live) {
         int n, ty0, tx0;
         decode(t, n, ty0, tx0);
         const rsrc_t xrs = make_rsrc(a.x + (long)n * a.H * a.W * 32, img);
@@ -395,11 +399,11 @@ __global__ __launch_bounds__(256) void k_conv3x3_c32(HaloArgs a)
             const int e = tid + 256 * it;
             const int px = min(e >> 3, HT_WP - 1), q = e & 7;
             const int iy = ty0 - 1 + px / HT_WW, ix = tx0 - 1 + px % HT_WW;
-            const bool ok = e < AQ && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            const bool ok = live && e < AQ && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
             sa[it] = bload4(xrs, ok ? (unsigned)((iy * a.W + ix) * 128 + 16 * q) : IG_OOB, 0);
         }
     };
-    load_window(sp);
+    load_window(sp, true);
     {
         float4 sb[9];
 #pragma unroll
@@ -430,7 +434,11 @@ __global__ __launch_bounds__(256) void k_conv3x3_c32(HaloArgs a)
             }
         }
         __syncthreads();
-        if (sp + step < nsp) load_window(sp + step);  // in flight during the K loop below
+        {
+            const bool more = sp + step < nsp;
+            load_window(more ? sp + step : sp, more);  // in flight during the K loop below
+        }
+        __builtin_amdgcn_sched_barrier(0);
 
         // ---- K loop: 9 taps x 4 groups of 8 channels, fragments one group ahead, no global load, no barrier ----
         f32x16 acc;

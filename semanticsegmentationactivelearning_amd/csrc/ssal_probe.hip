@@ -202,13 +202,52 @@ __global__ __launch_bounds__(256) void k_probe_tile_persistent(const float *x, f
     }
 }
 
+// modes 22 / 23: the 8 x 32 tile walked ROW BY ROW by its workgroup: the loads of row r+1 (2 float4 per thread) are
+// issued, then row r is stored -- what a row-streaming form of the fused kernels would put on the memory system
+// (mode 23: two rows per step, 4 float4 per thread)
+template <int RS>
+__global__ __launch_bounds__(256) void k_probe_tile_rows(const float *x, float *y, int H, int W, int spin)
+{
+    constexpr int C = 64, TH = 8, TW = 32, Q = RS * TW * C / 4 / 256;  // float4 per thread and step
+    const int tiles_x = W / TW, tiles_y = H / TH;
+    int b = blockIdx.x;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y; b /= tiles_y;
+    const long base = ((long)b * H * W + (long)(ty * TH) * W + tx * TW) * C;
+    auto off = [&](int step, int q) {
+        const int e = (int)threadIdx.x + 256 * q;            // float4 index inside the step's RS rows
+        const int row = e / (TW * C / 4), c4 = e % (TW * C / 4);
+        return base + ((long)(step * RS + row) * W) * C + 4 * c4;
+    };
+    float4 cur[Q], nxt[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) cur[q] = *reinterpret_cast<const float4 *>(x + off(0, q));
+#pragma unroll 1
+    for (int step = 0; step < TH / RS; ++step) {
+        if (step + 1 < TH / RS) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) nxt[q] = *reinterpret_cast<const float4 *>(x + off(step + 1, q));
+        }
+        if (spin > 0) {
+            float acc = cur[0].x;
+            const long t0 = __builtin_amdgcn_s_memtime();
+            while ((long)__builtin_amdgcn_s_memtime() - t0 < spin / (TH / RS)) acc = fmaf(acc, 1.0000001f, 1e-9f);
+            if (acc == 12345.678f) cur[0].x = acc;
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) *reinterpret_cast<float4 *>(y + off(step, q)) = cur[q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) cur[q] = nxt[q];
+    }
+}
+
 hipError_t launch_copy_probe(int mode, const float *x, float *y, int N, int H, int W, int spin, hipStream_t s)
 {
     if (H % 16 || W % 256) return hipErrorInvalidValue;
     const long n = (long)N * H * W * 64;
     static const char *names[] = {"probe linear", "probe tile frag", "probe tile coalesced", "probe tile frag+halo",
                                   "probe tile coalesced+halo"};
-    if (mode < 0 || mode > 21) return hipErrorInvalidValue;
+    if (mode < 0 || mode > 23) return hipErrorInvalidValue;
     ProfScope prof(mode <= 4 ? names[mode] : "probe tile shape", 0.0, 8.0 * n, s);
     const unsigned tiles = (unsigned)((long)N * (H / 8) * (W / 32));
     switch (mode) {
@@ -239,6 +278,8 @@ hipError_t launch_copy_probe(int mode, const float *x, float *y, int N, int H, i
     case 19: hipLaunchKernelGGL((k_probe_tile<true, false, 8, 32, 12000>), dim3(tiles), dim3(256), 0, s, x, y, H, W, spin); break;
     case 20: hipLaunchKernelGGL((k_probe_tile<true, false, 8, 32, 25000>), dim3(tiles), dim3(256), 0, s, x, y, H, W, spin); break;
     case 21: hipLaunchKernelGGL((k_probe_tile<true, false, 8, 32, 50000>), dim3(tiles), dim3(256), 0, s, x, y, H, W, spin); break;
+    case 22: hipLaunchKernelGGL((k_probe_tile_rows<1>), dim3(tiles), dim3(256), 0, s, x, y, H, W, spin); break;
+    case 23: hipLaunchKernelGGL((k_probe_tile_rows<2>), dim3(tiles), dim3(256), 0, s, x, y, H, W, spin); break;
     case 13: hipLaunchKernelGGL((k_probe_linear_u<2, true>), dim3((unsigned)((n / 4 + 511) / 512)), dim3(256), 0, s,
                                 (const float4 *)x, (float4 *)y, n / 4); break;
     }

@@ -13,7 +13,8 @@ names = ["linear", "tile 8x32 frag", "tile 8x32 coalesced", "tile 8x32 frag+halo
          "linear, 2 float4/thread batch", "linear, 16 float4/thread batch, slab order",
          "persistent 8x32 tiles, next tile prefetched, 768 WGs", "persistent 8x16 tiles, prefetched, 1024 WGs",
          "persistent 8x32 tiles, prefetched, 512 WGs", "persistent 8x16 tiles, prefetched, 2048 WGs",
-         "tile 8x32 frag, every 2nd first-round WG 12k cycles late", "same, 25k cycles late", "same, 50k cycles late"]
+         "tile 8x32 frag, every 2nd first-round WG 12k cycles late", "same, 25k cycles late", "same, 50k cycles late",
+         "tile 8x32 walked row by row (load row r+1, store row r)", "same, two rows per step"]
 only = [int(a) for a in sys.argv[2:]]
 def run(mode, spin, reps=20, out=y):
     _lib.check(L.ssal_debug_copy_probe(mode, _lib.dev_ptr(x), _lib.dev_ptr(out), n, h, w, spin, _lib.stream_ptr()))

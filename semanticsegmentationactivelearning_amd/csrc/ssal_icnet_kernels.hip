@@ -665,8 +665,9 @@ hipError_t launch_igemm(const float *x, int N, int H, int W, int Cin, const floa
             return hipGetLastError();
         }
     }
-    // 32-bit byte offsets inside the kernel: every tensor of one launch must stay below 4 GiB (split the batch)
-    if ((long)N * H * W * Cin * 4 >= (1L << 32) - 256 || a.M * Cout * 4 >= (1L << 32) - 256 || a.M >= (1L << 31) - 256)
+    // 32-bit byte offsets inside the kernel: every tensor of one launch must stay below 4 GiB (split the batch); the
+    // margin covers the per-chunk scalar offset (< 4 * Cin <= 8 KiB) that is added to a row offset by the hardware
+    if (Cin > 2048 || (long)N * H * W * Cin * 4 >= (1L << 32) - 16384 || a.M * Cout * 4 >= (1L << 32) - 256 || a.M >= (1L << 31) - 256)
         return hipErrorInvalidValue;
     a.tiles_m = cdiv_i(a.M, IG_BM);
     const int nb32 = a.CoutP / 32;

@@ -685,7 +685,9 @@ hipError_t launch_igemm(const float *x, int N, int H, int W, int Cin, const floa
     const double flops = 2.0 * (double)a.M * KH * KW * Cin * Cout;
     const double bytes = 4.0 * ((double)N * H * W * Cin + (double)a.M * Cout * (res ? 2.0 : 1.0) +
                                 (double)KH * KW * Cin * Cout);
-    ProfScope prof(NT == 4 ? "k_igemm<4>" : NT == 2 ? "k_igemm<2>" : "k_igemm<1>", flops, bytes, s);
+    // one profile row per kernel SYMBOL (rocprofv3 lists k_igemm<NT, false> and k_igemm<NT, true> separately)
+    ProfScope prof(up2 ? (NT == 4 ? "k_igemm<4,up2>" : NT == 2 ? "k_igemm<2,up2>" : "k_igemm<1,up2>")
+                       : (NT == 4 ? "k_igemm<4>" : NT == 2 ? "k_igemm<2>" : "k_igemm<1>"), flops, bytes, s);
 #define SSAL_IG(N_)                                                                         \
     if (up2) hipLaunchKernelGGL((k_igemm<N_, true>), dim3(grid), dim3(256), 0, s, a);      \
     else hipLaunchKernelGGL((k_igemm<N_, false>), dim3(grid), dim3(256), 0, s, a)

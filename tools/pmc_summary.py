@@ -19,7 +19,7 @@ def short(name):
     if n.startswith("k_bottleneck16"):
         return n.replace(" ", "")
     if n.startswith("k_igemm"):
-        return n.split(",")[0] + ">"  # k_igemm<4, true> -> k_igemm<4>
+        return n.split(",")[0] + (",up2>" if "true" in n else ">")  # k_igemm<4, true> -> k_igemm<4,up2>;  <4, false> -> k_igemm<4>
     return n.split("<")[0]
 
 

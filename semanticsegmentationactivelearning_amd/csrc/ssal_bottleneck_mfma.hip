@@ -1198,7 +1198,9 @@ hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W,
     const double pix = (double)N * H * W;
     const double f = Cin / 4.0;
     const double taps = asym ? 10.0 : 9.0;
-    ProfScope prof(asym ? "k_bottleneck_mfma_asym" : "k_bottleneck_mfma",
+    // one profile row per kernel symbol, as rocprofv3 lists them
+    ProfScope prof(asym ? (wide ? "k_bottleneck_mfma_asym<32>" : "k_bottleneck_mfma_asym<16>")
+                        : (wide ? "k_bottleneck_mfma<32>" : "k_bottleneck_mfma<16>"),
                    2.0 * pix * (Cin * f + taps * f * f + f * Cin),
                    4.0 * (2.0 * pix * Cin + Cin * f * 2.0 + taps * f * f), s);
     if (asym) {

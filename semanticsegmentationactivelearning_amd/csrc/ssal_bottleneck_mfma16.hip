@@ -657,7 +657,8 @@ hipError_t launch_bottleneck_mfma16(const BnkArgs &a0, int Cin, hipStream_t s)
     if (grid <= 0 || grid > 0x7fffffffL) return hipErrorInvalidValue;
     a.trace = (g_trace_buf && grid * 4 * 16 * 8 <= g_trace_bytes) ? g_trace_buf : nullptr;
     const double pix = (double)a.N * a.H * a.W, f = Cin / 4.0;
-    ProfScope prof(Cin == 64 ? "k_bottleneck16<64,16>" : "k_bottleneck16<16,4>",
+    ProfScope prof(Cin == 64 ? (wide ? "k_bottleneck16<32,64,16>" : "k_bottleneck16<16,64,16>")
+                             : (wide ? "k_bottleneck16<32,16,4>" : "k_bottleneck16<16,16,4>"),  // = the kernel symbols
                    2.0 * pix * (Cin * f + 9.0 * f * f + f * Cin), 4.0 * 2.0 * pix * Cin, s);
     dim3 G((unsigned)grid), B(256);
     if (Cin == 64) {

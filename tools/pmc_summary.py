@@ -16,7 +16,7 @@ os.makedirs(DST, exist_ok=True)
 def short(name):
     """kernel names as ssal_profile_collect (bench.py's roofline leg) reports them"""
     n = name.split("(")[0].replace("void ", "").replace("ssal::", "")
-    if n.startswith("k_bottleneck16"):
+    if n.startswith("k_bottleneck16") or n.startswith("k_bottleneck_mfma"):
         return n.replace(" ", "")
     if n.startswith("k_igemm"):
         return n.split(",")[0] + (",up2>" if "true" in n else ">")  # k_igemm<4, true> -> k_igemm<4,up2>;  <4, false> -> k_igemm<4>

@@ -33,6 +33,13 @@ namespace ssal {
 constexpr int F = 32;         // bottleneck width
 constexpr int C = 128;        // block channels
 constexpr int PSTR = F + 2;   // LDS pixel stride in dwords: conflict-free ds_read_b64 / ds_write_b32
+// Channel order inside an LDS pixel row: every group of 8 channels is stored as [c0 c2 c4 c6 | c1 c3 c5 c7], so the
+// float2 a lane half reads at 8g + 4h (+2) holds, register by register, the (k = 2s | k = 2s + 1) pair of MFMA step s:
+// no v_permlane32_swap between the LDS read and the MFMA.  (A swap costs ~13 SIMD cycles and, like every vector
+// instruction, executes INSTEAD of the fp32 MFMAs, never beside them: tools/mfma_peak.py.)
+__device__ __forceinline__ int kperm(int c) { return (c & ~7) | ((c & 1) << 2) | ((c & 7) >> 1); }
+// the sq-th float2 (sq = 0..7) of a lane half's operand sequence inside a permuted row: steps 2sq, 2sq + 1
+__device__ __forceinline__ int kperm_rd(int sq, int h) { return 8 * (sq >> 1) + 4 * h + 2 * (sq & 1); }
 constexpr int PMAX = 352;     // >= (TH+2)*(TW+2) rounded up to a multiple of 32
 
 
@@ -72,7 +79,7 @@ __device__ __forceinline__ void proj_to_lds(const Args &a, const float *ximg, fl
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int qi = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (qi < prows) P[qi * PSTR + j] = 0.0f;
+                if (qi < prows) P[qi * PSTR + kperm(j)] = 0.0f;
             }
             continue;
         }
@@ -115,7 +122,7 @@ __device__ __forceinline__ void proj_to_lds(const Args &a, const float *ximg, fl
             const int ri = (i & 3) + 8 * (i >> 2) + 4 * h;
             const bool ok = (vmask >> ri) & 1ull;
             const float v = ok ? prelu1(fmaf(acc[i], bs, bt), ba) : 0.0f;
-            if (mt * 32 + ri < prows) P[(mt * 32 + ri) * PSTR + j] = v;
+            if (mt * 32 + ri < prows) P[(mt * 32 + ri) * PSTR + kperm(j)] = v;
         }
     }
 }
@@ -141,17 +148,15 @@ __device__ __forceinline__ void conv5x1_to_lds(const BnkArgs &a, const float *P,
         auto load_tap = [&](int kh, float (&w)[16], float2 (&pv)[8]) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) w[k] = bload(wrs, lo, kh * (F * F * 4) + k * 256);  // W0[kh][2k + h][j]
-            const float *pq = P + (u + kh * HWP) * PSTR + 2 * h;  // result pixel u = (r, c') reads P rows r + kh
+            const float *pq = P + (u + kh * HWP) * PSTR;  // result pixel u = (r, c') reads P rows r + kh
 #pragma unroll
-            for (int sq = 0; sq < 8; ++sq) pv[sq] = *reinterpret_cast<const float2 *>(pq + 4 * sq);
+            for (int sq = 0; sq < 8; ++sq) pv[sq] = *reinterpret_cast<const float2 *>(pq + kperm_rd(sq, h));
         };
         auto run_tap = [&](const float (&w)[16], const float2 (&pv)[8]) {
 #pragma unroll
-            for (int sq = 0; sq < 8; ++sq) {
-                float a0 = pv[sq].x, a1 = pv[sq].y;
-                swap32(a0, a1);  // a0 = ci(4sq | 4sq+1), a1 = ci(4sq+2 | 4sq+3)
-                acc = mfma32(a0, w[2 * sq], acc);
-                acc = mfma32(a1, w[2 * sq + 1], acc);
+            for (int sq = 0; sq < 8; ++sq) {  // permuted rows: .x = ci(4sq | 4sq+1), .y = ci(4sq+2 | 4sq+3)
+                acc = mfma32(pv[sq].x, w[2 * sq], acc);
+                acc = mfma32(pv[sq].y, w[2 * sq + 1], acc);
             }
         };
         load_tap(0, wA, pA);
@@ -170,7 +175,7 @@ __device__ __forceinline__ void conv5x1_to_lds(const BnkArgs &a, const float *P,
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int ri = (i & 3) + 8 * (i >> 2) + 4 * h;
-            R[(mt * 32 + ri) * PSTR + j] = acc[i];
+            R[(mt * 32 + ri) * PSTR + kperm(j)] = acc[i];
         }
     }
 }
@@ -206,17 +211,15 @@ __device__ __forceinline__ void conv_tile_q(const Args &a, const float *S, const
             slot += soff;
             slot = slot < 0 ? slot + WRAP : slot;
         }
-        const float *pq = S + slot * PSTR + 2 * h;
+        const float *pq = S + slot * PSTR;
 #pragma unroll
-        for (int sq = 0; sq < 8; ++sq) p[sq] = *reinterpret_cast<const float2 *>(pq + 4 * sq);
+        for (int sq = 0; sq < 8; ++sq) p[sq] = *reinterpret_cast<const float2 *>(pq + kperm_rd(sq, h));
     };
     auto run_tap = [&](const float (&w)[16], const float2 (&p)[8]) {
 #pragma unroll
-        for (int sq = 0; sq < 8; ++sq) {
-            float b0 = p[sq].x, b1 = p[sq].y;
-            swap32(b0, b1);  // b0 = ci(4sq | 4sq+1), b1 = ci(4sq+2 | 4sq+3)
-            acc = mfma32(w[2 * sq], b0, acc);      // W[tap][ci = 4sq + h][co = j]
-            acc = mfma32(w[2 * sq + 1], b1, acc);  // W[tap][ci = 4sq + 2 + h][co = j]
+        for (int sq = 0; sq < 8; ++sq) {  // permuted rows: .x = ci(4sq | 4sq+1), .y = ci(4sq+2 | 4sq+3)
+            acc = mfma32(w[2 * sq], p[sq].x, acc);      // W[tap][ci = 4sq + h][co = j]
+            acc = mfma32(w[2 * sq + 1], p[sq].y, acc);  // W[tap][ci = 4sq + 2 + h][co = j]
         }
     };
     load_tap(0, wA, pA);
@@ -589,7 +592,7 @@ __global__ __launch_bounds__(256, 2) void k_downsample_mfma(DownArgs a)
         for (int i = 0; i < 16; ++i) {  // rows = pixels (registers), cols = co (lanes)
             const int ri = (i & 3) + 8 * (i >> 2) + 4 * h;
             const bool ok = (vmask >> ri) & 1u;
-            P[qf(ri) * PSTR + j] = ok ? prelu1(fmaf(acc[i], bs, bt), ba) : 0.0f;  // exact zero outside the image
+            P[qf(ri) * PSTR + kperm(j)] = ok ? prelu1(fmaf(acc[i], bs, bt), ba) : 0.0f;  // exact zero outside the image
         }
     };
 
@@ -811,7 +814,7 @@ __global__ __launch_bounds__(256, 2) void k_upsample_mfma(UpArgs a)
         for (int i = 0; i < 16; ++i) {  // rows = pixels (registers), cols = co (lanes)
             const int ri = (i & 3) + 8 * (i >> 2) + 4 * h;
             const bool ok = (vmask >> ri) & 1u;
-            P[qf(ri) * PSTR + j] = ok ? prelu1(fmaf(acc[i], bs, bt), ba) : 0.0f;  // exact zero outside the image
+            P[qf(ri) * PSTR + kperm(j)] = ok ? prelu1(fmaf(acc[i], bs, bt), ba) : 0.0f;  // exact zero outside the image
         }
     };
 
@@ -871,17 +874,15 @@ __global__ __launch_bounds__(256, 2) void k_upsample_mfma(UpArgs a)
                 const int dr = slot < 4 ? 1 - (slot >> 1) : 1, dc = 1 - (slot & 1);
 #pragma unroll
                 for (int q = 0; q < 16; ++q) w[q] = bload(wsrs, wplo, (slot * 16 + q) * 256);  // ws[slot][2q + h][j]
-                const float *pq = P + ((r + dr) * HW2 + (c + dc)) * PSTR + 2 * h;
+                const float *pq = P + ((r + dr) * HW2 + (c + dc)) * PSTR;
 #pragma unroll
-                for (int sq = 0; sq < 8; ++sq) pv[sq] = *reinterpret_cast<const float2 *>(pq + 4 * sq);
+                for (int sq = 0; sq < 8; ++sq) pv[sq] = *reinterpret_cast<const float2 *>(pq + kperm_rd(sq, h));
             };
             auto run_slot = [&](f32x16 &acc, const float (&w)[16], const float2 (&pv)[8]) {
 #pragma unroll
-                for (int sq = 0; sq < 8; ++sq) {
-                    float b0 = pv[sq].x, b1 = pv[sq].y;
-                    swap32(b0, b1);
-                    acc = mfma32(w[2 * sq], b0, acc);
-                    acc = mfma32(w[2 * sq + 1], b1, acc);
+                for (int sq = 0; sq < 8; ++sq) {  // permuted rows: no re-pairing
+                    acc = mfma32(w[2 * sq], pv[sq].x, acc);
+                    acc = mfma32(w[2 * sq + 1], pv[sq].y, acc);
                 }
             };
             // slots 0..3 = P(i,j), P(i,j-1), P(i-1,j), P(i-1,j-1) -> [ee|eo];  4, 5 = P(i,j), P(i,j-1) -> [oe|oo]
@@ -1015,6 +1016,31 @@ __global__ __launch_bounds__(256) void k_mfma_peak(float *out, int iters)
             c0 = mfma32(a, b, c0); c0 = mfma32(b, a, c0); c0 = mfma32(a, b, c0); c0 = mfma32(b, a, c0);
         }
         out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c0[5];
+    } else if (SHAPE == 332 || SHAPE == 432) {
+        // four independent accumulators + 8 (332) / 16 (432) independent v_fma_f32 per four MFMAs: does vector work of
+        // the same wave / of co-resident waves execute in the shadow of the matrix pipe, or does it add to it?
+        f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = a + k;
+        for (int i = 0; i < iters; ++i) {
+            c0 = mfma32(a, b, c0);
+#pragma unroll
+            for (int k = 0; k < (SHAPE == 432 ? 4 : 2); ++k) v[k] = fmaf(v[k], 1.0000001f, b);
+            c1 = mfma32(a, b, c1);
+#pragma unroll
+            for (int k = 0; k < (SHAPE == 432 ? 4 : 2); ++k) v[2 + k] = fmaf(v[2 + k], 1.0000001f, b);
+            c2 = mfma32(a, b, c2);
+#pragma unroll
+            for (int k = 0; k < (SHAPE == 432 ? 4 : 2); ++k) v[4 + (k & 3)] = fmaf(v[4 + (k & 3)], 1.0000001f, b);
+            c3 = mfma32(a, b, c3);
+#pragma unroll
+            for (int k = 0; k < (SHAPE == 432 ? 4 : 2); ++k) v[(6 + k) & 7] = fmaf(v[(6 + k) & 7], 1.0000001f, b);
+        }
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += v[k];
+        out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3] + t;
     } else if (SHAPE == 232) {
         f32x16 c0 = {0};
         float p = a, q = b;
@@ -1037,11 +1063,15 @@ hipError_t launch_mfma_peak(int shape, int blocks, int iters, float *out, hipStr
     const bool is32 = shape != 16;
     const double flop = (double)blocks * 4 /*waves*/ * iters * 4.0 * (is32 ? 4096.0 : 2048.0);
     const char *nm = shape == 32 ? "k_mfma_peak<32x32x2 4acc>" : shape == 132 ? "k_mfma_peak<32x32x2 1chain>"
-                   : shape == 232 ? "k_mfma_peak<32x32x2 1chain+swap>" : "k_mfma_peak<16x16x4 4acc>";
+                   : shape == 232 ? "k_mfma_peak<32x32x2 1chain+swap>"
+                   : shape == 332 ? "k_mfma_peak<32x32x2 4acc + 8 v_fma / 4 mfma>"
+                   : shape == 432 ? "k_mfma_peak<32x32x2 4acc + 16 v_fma / 4 mfma>" : "k_mfma_peak<16x16x4 4acc>";
     ProfScope prof(nm, flop, 0.0, s);
     if (shape == 32) hipLaunchKernelGGL(k_mfma_peak<32>, dim3(blocks), dim3(256), 0, s, out, iters);
     else if (shape == 132) hipLaunchKernelGGL(k_mfma_peak<132>, dim3(blocks), dim3(256), 0, s, out, iters);
     else if (shape == 232) hipLaunchKernelGGL(k_mfma_peak<232>, dim3(blocks), dim3(256), 0, s, out, iters);
+    else if (shape == 332) hipLaunchKernelGGL(k_mfma_peak<332>, dim3(blocks), dim3(256), 0, s, out, iters);
+    else if (shape == 432) hipLaunchKernelGGL(k_mfma_peak<432>, dim3(blocks), dim3(256), 0, s, out, iters);
     else hipLaunchKernelGGL(k_mfma_peak<16>, dim3(blocks), dim3(256), 0, s, out, iters);
     return hipGetLastError();
 }

@@ -449,6 +449,18 @@ def test_score_is_bitwise_reproducible(enet_c3k19):
     assert torch.equal(a, c)
 
 
+def test_repeated_scoring_is_bitwise_stable_at_bench_tile_counts(enet_c3k19):
+    """soak: 25 back-to-back passes over the same 2 x 512 x 1024 batch (thousands of workgroups per launch, both tile
+    widths of the 128-channel kernels through the dilation-16 layers) give identical scores, labels and confidences"""
+    net, _ = enet_c3k19
+    x = syn.synth_frames_device(300, 2, 512, 1024, 3)
+    s0, e0 = net.score(x, "entropy", return_label=True, return_confidence=True)
+    s0, l0, c0 = s0.clone(), e0["label"].clone(), e0["confidence"].clone()
+    for _ in range(24):
+        s, e = net.score(x, "entropy", return_label=True, return_confidence=True)
+        assert torch.equal(s, s0) and torch.equal(e["label"], l0) and torch.equal(e["confidence"], c0)
+
+
 def test_weight_update_is_picked_up(enet_c3k19):
     net, P = enet_c3k19
     x = frames([1], 32, 32, 3)

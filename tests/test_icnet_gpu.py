@@ -353,3 +353,17 @@ def test_icnet_random_sizes_and_batches(icnet19, seed):
         s = net.score(dev(x), "margin")
         wm = orc.score_logits(want, "margin")[0]
         report_diff("margin mean %dx%dx%d" % (n, h, w), s.cpu().numpy(), wm, exact=False, atol=1e-6)
+
+
+def test_repeated_scoring_is_bitwise_stable_at_bench_tile_counts(icnet19):
+    """soak: 25 back-to-back scoring passes of the same 2 x 512 x 1024 batch (every kernel runs with thousands of
+    workgroups, the implicit-GEMM loops with up to 72 chunks and LDS double buffers written from inside the matrix
+    section) must give the same float64 scores and the same per-pixel labels bit for bit -- a race between a wave still
+    reading an LDS buffer and another one refilling it would show up here as a flipped pixel"""
+    net, _ = icnet19
+    x = syn.synth_frames_device(300, 2, 512, 1024, 3)
+    s0, e0 = net.score(x, "margin", return_label=True, return_confidence=True)
+    s0, l0, c0 = s0.clone(), e0["label"].clone(), e0["confidence"].clone()
+    for _ in range(24):
+        s, e = net.score(x, "margin", return_label=True, return_confidence=True)
+        assert torch.equal(s, s0) and torch.equal(e["label"], l0) and torch.equal(e["confidence"], c0)

@@ -1,27 +1,42 @@
 #!/usr/bin/env python3
 """bench.py -- unlabelled-pool images/sec scored (ENet, 1024x2048) on N MI355X GPUs.
 
-Workload (BASELINE.json configs[1] / [2]): a pool of 2975 synthetic Cityscapes-shaped frames
+Headline workload (BASELINE.json configs[1] / [2]): a pool of 2975 synthetic Cityscapes-shaped frames
 (1024x2048x3 fp32 NHWC, device-resident before the timed region), ENet(19 classes) with seeded
 synthetic weights, entropy acquisition, batches of 8 (reference conf/*.json:2).  One "step" = one
 batch of 8 frames through the fused path: ENet forward + per-pixel softmax-entropy + float64
-per-image mean.  With N > 1 the pool is sharded over the ranks (one process per GPU, weak scaling:
-every rank scores `steps` batches of its own shard) and the per-image (index, score) pairs are
-merged by ONE RCCL all-gather followed by the float32 scatter + top-128 argpartition on every
-rank; that merge is inside the timed region.
+per-image mean.  With N > 1 the pool is sharded over the ranks (one process per GPU) and the per-image
+(index, score) pairs are merged by ONE RCCL all-gather followed by the float32 scatter + top-128
+argpartition on every rank; that merge is inside the timed region.
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (dominant kernel,
-HIP-event timed live on the launch stream in a separate profiling pass) and `cpu_baseline` (the
-torch-CPU restatement of the reference path, timed on this box's host cores; N=1 only).
+Scaling mode: N = 1 times exactly K steps.  N > 1 defaults to STRONG scaling, the statement north_star / SURVEY 8(d)
+make ("images/s = 2975 / t", ">= 6x at 8 GPUs"): the fixed 2975-frame pool is split over the ranks, `value` = 2975 /
+max-over-ranks time, `steps` = the batches each rank ran (`requested_steps` keeps K); the weak figure (every rank
+scores exactly K batches of its shard) is timed right after and reported beside it as `weak`.  `--scaling weak`
+makes the weak figure the headline instead.
+
+Rank 0 prints ONE JSON line (contract in the task statement) carrying
+  `roofline`        dominant kernel, HIP-event timed live on the launch stream in a separate profiling pass,
+  `roofline_all`    the same figures for EVERY kernel symbol of the pass (avg us, algorithmic flops / bytes per launch,
+                    bound, frac, PMC traffic per launch from the committed profiles/<round>_pmc passes),
+  `score_digest`    SHA-256 of the float64 scores of the frames scored in the timed region, compared with the digest of
+                    the same frames in the committed table tests/golden/pool_scores.npz (a GPU run whose entries the
+                    parity tests tie to the C oracle); a mismatch makes the bench exit non-zero,
+  `secondary`       (N = 1) short legs of the other single-GPU BASELINE configs: c4 = configs[3] ICNet / margin,
+                    c5 = configs[4] ENet RGB+NIR, 6 classes / entropy -- each with value, ms_per_step, roofline, digest,
+  `cpu_baseline`    the torch-CPU restatement of the reference path, timed on this box's host cores (N = 1 only).
 """
 import argparse
+import datetime
+import hashlib
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -37,6 +52,10 @@ POOL = 2975          # Cityscapes train split size (BASELINE.json configs[1])
 TOP_K = 128          # BASELINE.json configs[2]
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector == fp32-input MFMA peak
+SCORE_TABLE = os.path.join(ROOT, "tests", "golden", "pool_scores.npz")
+PMC_ROUNDS = ("r03", "r02")  # newest committed PMC pass first
+ICNET_NOTE = ("ICNet as pinned by ICNET_SPEC.md -- the reference's models/icnet/icnet.py is an empty class: parity "
+              "unpinned AND undefined")
 
 
 def log(msg):
@@ -48,7 +67,32 @@ def log(msg):
 _T0 = time.perf_counter()
 
 
-def parse():
+class Watchdog:
+    """`with Watchdog(seconds, what):` -- if the block has not finished after `seconds`, say so on stderr and leave the
+    process with exit code 3 (a rank that never arrives must not hang the job: collectives block inside C code, so
+    an exception cannot be raised into them; os._exit is the only way out)."""
+
+    def __init__(self, seconds, what):
+        self.seconds, self.what, self._done = float(seconds), what, threading.Event()
+
+    def _run(self):
+        if not self._done.wait(self.seconds):
+            print("[bench] TIMEOUT after %.0f s in: %s (rank %s of %s) -- a rank is missing or hung; exiting 3"
+                  % (self.seconds, self.what, os.environ.get("RANK", "0"), os.environ.get("WORLD_SIZE", "1")),
+                  file=sys.stderr, flush=True)
+            os._exit(3)
+
+    def __enter__(self):
+        if self.seconds > 0:
+            threading.Thread(target=self._run, daemon=True).start()
+        return self
+
+    def __exit__(self, *exc):
+        self._done.set()
+        return False
+
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=372)   # 372 batches of 8 = the whole 2975-frame pool
@@ -59,9 +103,10 @@ def parse():
     ap.add_argument("--classes", type=int, default=19)
     ap.add_argument("--channels", type=int, default=3)
     ap.add_argument("--model", choices=["enet", "icnet"], default="enet",
-                    help="enet: BASELINE configs[1] (the metric's workload); icnet: configs[3] (ICNet multi-scale, use "
-                         "--measure margin), architecture pinned in ICNET_SPEC.md")
+                    help="enet: BASELINE configs[1] (the metric's workload); icnet: configs[3] (ICNet multi-scale, "
+                         "margin), architecture pinned in ICNET_SPEC.md")
     ap.add_argument("--measure", default=None, help="entropy | margin | confidence (default: entropy, margin for icnet)")
+    ap.add_argument("--weights-seed", type=int, default=0)
     ap.add_argument("--input-dtype", choices=["f32", "u8"], default="f32",
                     help="resident frames: float32 in [0,1] (the reference's model input) or the decoded uint8 "
                          "frames, converted inside the Initial kernel (same bits out)")
@@ -70,16 +115,54 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak: every rank scores --steps batches of its own shard (per-GPU work fixed); strong: the "
-                         "whole 2975-frame pool is split over the ranks (total work fixed, --steps is ignored and "
-                         "reported as the batches rank 0 ran), value = 2975 / t")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C4 / C5 legs (profiling runs)")
+    ap.add_argument("--secondary-steps", type=int, default=24)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="default: strong when WORLD_SIZE > 1 (the fixed 2975-frame pool split over the ranks, value = "
+                         "2975 / t; the weak figure is reported beside it), weak at N = 1 (exactly --steps steps)")
+    ap.add_argument("--dist-timeout", type=float, default=180.0,
+                    help="seconds a rendezvous / barrier / collective may take before the process exits non-zero")
     ap.add_argument("--allow-nondefault-knobs", action="store_true",
                     help="measurement runs only (tools/*.sh with a -DSSAL_MEASURE library): time the library although "
                          "ssal_debug_get_knobs() says a switch is off its default; the JSON line still reports them")
-    return ap.parse_args()
+    ap.add_argument("--allow-digest-mismatch", action="store_true",
+                    help="measurement builds whose results are invalid by construction (ablation): report, do not fail")
+    return ap.parse_args(argv)
 
 
+# ---- score table / digest ---------------------------------------------------------------------------------
+def table_key(model, c, classes, h, w, measure, seed):
+    return "%s_c%dk%d_%dx%d_%s_seed%d" % (model, c, classes, h, w, measure, seed)
+
+
+def load_score_table(key):
+    try:
+        with np.load(SCORE_TABLE) as z:
+            return np.array(z[key], dtype=np.float64) if key in z.files else None
+    except Exception:
+        return None
+
+
+def score_digest(index, score, key):
+    """SHA-256 of the float64 scores (frame-id order) of the frames actually scored, vs the committed table"""
+    index = np.asarray(index, dtype=np.int64)
+    score = np.asarray(score, dtype=np.float64)
+    keep = index >= 0
+    index, score = index[keep], score[keep]
+    first = np.unique(index, return_index=True)[1]  # a wrapped batch list may score a frame twice: same bits, keep one
+    index, score = index[first], score[first]
+    out = {"frames": int(len(index)), "sha256": hashlib.sha256(np.ascontiguousarray(score).tobytes()).hexdigest(),
+           "table": "tests/golden/pool_scores.npz[%s]" % key, "expected_sha256": None, "match": None}
+    table = load_score_table(key)
+    if table is not None and len(index) and index.max() < len(table):
+        want = table[index]
+        out["expected_sha256"] = hashlib.sha256(np.ascontiguousarray(want).tobytes()).hexdigest()
+        out["match"] = bool(out["sha256"] == out["expected_sha256"])
+        out["max_abs_diff"] = float(np.max(np.abs(score - want))) if not out["match"] else 0.0
+    return out
+
+
+# ---- CPU baseline -----------------------------------------------------------------------------------------
 def cpu_baseline(P, h, w, c, measure, budget_s, c1=None, model="enet"):
     """torch-CPU restatement of the reference path (oracle/torch_restatement.py) on a bounded
     sample: single 1024x2048 frames, 1 warm-up + as many repeats as fit the budget (>= 2)."""
@@ -131,14 +214,179 @@ def cpu_baseline(P, h, w, c, measure, budget_s, c1=None, model="enet"):
     return out
 
 
-def main():
-    args = parse()
+# ---- roofline ---------------------------------------------------------------------------------------------
+def load_pmc(model):
+    for rnd in PMC_ROUNDS:
+        try:
+            return rnd, json.load(open(os.path.join(ROOT, "profiles", "%s_pmc" % rnd, "traffic_%s.json" % model)))
+        except Exception:
+            continue
+    return None, {}
+
+
+def kernel_roofline(name, d, reps, pmc):
+    """one profile row -> roofline figures; d = {"launches", "ms", "flops", "bytes"} summed over `reps` batches"""
+    sec = d["ms"] * 1e-3
+    n = max(d["launches"], 1)
+    ridge = FP32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+    ai = d["flops"] / d["bytes"] if d["bytes"] > 0 else float("inf")
+    if d["bytes"] <= 0 and d["flops"] <= 0:
+        bound, achieved, peak, unit = "latency", None, None, None
+    elif ai >= ridge:
+        bound, achieved, peak, unit = "mfma", d["flops"] / sec / 1e12, FP32_PEAK_TFLOPS, "TFLOP/s"
+    else:
+        bound, achieved, peak, unit = "hbm", d["bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s"
+    traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
+    # "mfma" is the schema's name for the compute roof; the fp32 VECTOR peak equals the fp32 MFMA peak on this part
+    # (157.3 TFLOP/s), and these two kernels run their FLOPs on packed VALU FMAs, not on the matrix cores
+    pipe = None if bound != "mfma" else ("valu (v_pk_fma_f32)" if name.startswith(("k_final_score", "k_upscore", "k_conv_first")) else "mfma")
+    return {"bound": bound, "pipe": pipe, "achieved": achieved, "peak": peak, "unit": unit,
+            "frac": (achieved / peak) if achieved is not None else None, "traffic": traffic,
+            "traffic_over_algorithmic": (traffic / (d["bytes"] / n)) if (traffic and d["bytes"] > 0) else None,
+            "avg_us": 1e3 * d["ms"] / n, "launches_per_batch": d["launches"] // reps,
+            "flops": d["flops"] / n, "bytes": d["bytes"] / n, "ms_per_batch": d["ms"] / reps}
+
+
+def roofline_leg(net, batch, measure, model, reps=3):
+    """separate pass, outside every timed region: ssal_profile_enable(1) brackets each launch with HIP events on the
+    launch stream.  -> (roofline of the dominant kernel, roofline_all)"""
+    import torch
+    from semanticsegmentationactivelearning_amd import _lib
+    _lib.profile_enable(True)
+    try:
+        for _ in range(reps):
+            net.score(batch, measure=measure)
+        torch.cuda.synchronize()
+        prof = _lib.profile_collect()
+    finally:
+        _lib.profile_enable(False)
+    rnd, pmc = load_pmc(model)
+    rows = {k: kernel_roofline(k, v, reps, pmc.get(k)) for k, v in sorted(prof.items())}
+    dom = max(prof, key=lambda k: prof[k]["ms"])
+    d, r = prof[dom], rows[dom]
+    total_ms = sum(v["ms"] for v in prof.values())
+    sec = d["ms"] * 1e-3
+    roof = {"kernel": dom, "bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"],
+            "frac": r["frac"], "traffic": r["traffic"], "traffic_source": ("profiles/%s_pmc" % rnd) if rnd else None,
+            "algorithmic_bytes_per_launch": r["bytes"], "algorithmic_flops_per_launch": r["flops"],
+            "avg_launch_us": r["avg_us"], "launches_per_batch": r["launches_per_batch"],
+            "share_of_gpu_time": d["ms"] / total_ms,
+            "arithmetic_intensity_flop_per_byte": d["flops"] / d["bytes"] if d["bytes"] > 0 else None,
+            "achieved_tflops": d["flops"] / sec / 1e12, "achieved_gbs": d["bytes"] / sec / 1e9,
+            "per_kernel_ms_per_batch": {k: v["ms"] / reps for k, v in sorted(prof.items())}}
+    # whole pass against the sum of its kernels' binding floors
+    floor_ms = 0.0
+    for k, v in prof.items():
+        floor_ms += max(v["flops"] / (FP32_PEAK_TFLOPS * 1e12), v["bytes"] / (HBM_PEAK_GBS * 1e9)) * 1e3 / reps
+    roof["pass_ms_per_batch"] = total_ms / reps
+    roof["pass_floor_ms_per_batch"] = floor_ms
+    roof["pass_frac_of_kernel_floors"] = floor_ms / (total_ms / reps) if total_ms > 0 else None
+    return roof, rows
+
+
+# ---- one scoring leg ----------------------------------------------------------------------------------------
+class Leg:
+    """model + resident shard batches + the timed ranking pass over them"""
+
+    def __init__(self, args, ctx, model, classes, c, measure, seed, input_dtype="f32"):
+        import torch
+        import semanticsegmentationactivelearning_amd as ssal
+        from semanticsegmentationactivelearning_amd import synthetic as syn
+        self.args, self.ctx, self.model, self.classes, self.c, self.measure, self.seed = args, ctx, model, classes, c, measure, seed
+        self.h, self.w, self.bs = args.height, args.width, args.batch
+        if model == "icnet":
+            self.net = ssal.ICNet(classes)
+            self.net.build((None, None, None, c))
+            syn.randomize_icnet(self.net, seed=seed)
+        else:
+            self.net = ssal.ENet(classes)
+            self.net.build((None, None, None, c))
+            syn.randomize_enet(self.net, seed=seed)
+        self.torch, self.syn = torch, syn
+        self.input_dtype = input_dtype
+        self.batches = []
+
+    def make_resident(self, n_batches):
+        """this rank's strided shard of the pool, device-resident before any clock starts"""
+        from semanticsegmentationactivelearning_amd import active_learning as al
+        torch, syn, ctx = self.torch, self.syn, self.ctx
+        positions = al.shard_positions(POOL, ctx["rank"], ctx["world"])
+        self.positions = positions[positions >= 0]
+        self.n_batches_shard = (len(self.positions) + self.bs - 1) // self.bs
+        in_dtype = torch.uint8 if self.input_dtype == "u8" else torch.float32
+        bytes_per_batch = self.bs * self.h * self.w * self.c * (1 if self.input_dtype == "u8" else 4)
+        max_resident = max(1, int(self.args.resident_gib * 2 ** 30 // bytes_per_batch))
+        n_resident = min(n_batches, self.n_batches_shard, max_resident)
+        for b in range(len(self.batches), n_resident):
+            ids = self.positions[b * self.bs:(b + 1) * self.bs]
+            buf = torch.empty((len(ids), self.h, self.w, self.c), dtype=in_dtype, device=ctx["dev"])
+            # strided shard: frame ids are not consecutive when world > 1 -> one generator call per frame
+            if ctx["world"] == 1:
+                syn.synth_frames_device(int(ids[0]), len(ids), self.h, self.w, self.c, out=buf)
+            else:
+                for j, f in enumerate(ids):
+                    syn.synth_frames_device(int(f), 1, self.h, self.w, self.c, out=buf[j:j + 1])
+            self.batches.append((buf, torch.as_tensor(ids, device=ctx["dev"])))
+        torch.cuda.synchronize()
+        self.bytes_per_batch = bytes_per_batch
+        return len(self.batches)
+
+    def run_steps(self, k, first):
+        torch = self.torch
+        idx_chunks, score_chunks, frames = [], [], 0
+        for s in range(k):
+            xb, ib = self.batches[(first + s) % len(self.batches)]
+            score_chunks.append(self.net.score(xb, measure=self.measure))
+            idx_chunks.append(ib)
+            frames += xb.shape[0]
+        return torch.cat(idx_chunks), torch.cat(score_chunks), frames
+
+    def merge_and_select(self, index, score, pad_steps):
+        """ONE collective: every rank pads its (index, score) shard locally to pad_steps * batch entries (the same number on
+        every rank; a shard's last batch may be short) and all-gathers it; then the float32 scatter + top-k on the host"""
+        from semanticsegmentationactivelearning_amd import active_learning as al
+        if self.ctx["use_dist"]:
+            index, score = al.pad_to_length(index, score, pad_steps * self.bs)
+        all_index, all_score = al.all_gather_scores(index, score)
+        all_index, all_score = all_index.cpu().numpy(), all_score.cpu().numpy()
+        low, _ = al.finish_ranking(all_index, all_score, POOL, np.arange(POOL), TOP_K)
+        return low, all_index, all_score
+
+    def timed(self, steps, first, what):
+        """barrier + synchronize | exactly `steps` steps + the merge | synchronize + barrier; max over ranks"""
+        import torch.distributed as dist
+        torch, ctx = self.torch, self.ctx
+        with Watchdog(self.args.dist_timeout + 60.0 + 0.1 * steps, "timed region (%s)" % what):
+            if ctx["use_dist"]:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            index, score, frames = self.run_steps(steps, first)
+            low, all_index, all_score = self.merge_and_select(index, score, steps)
+            torch.cuda.synchronize()
+            if ctx["use_dist"]:
+                dist.barrier()
+            elapsed = time.perf_counter() - t0
+            t = torch.tensor([elapsed, float(frames)], dtype=torch.float64,
+                             device="cpu" if ctx["backend"] == "gloo" else ctx["dev"])
+            if ctx["use_dist"]:
+                tmax = t.clone()
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                elapsed, total_frames = float(tmax[0]), float(t[1])
+            else:
+                total_frames = float(frames)
+        log("%s: %d steps, %.0f frames over all ranks in %.3f s (max over ranks)" % (what, steps, total_frames, elapsed))
+        return {"elapsed": elapsed, "frames": total_frames, "steps": steps, "low": low,
+                "index": all_index, "score": all_score}
+
+    def key(self):
+        return table_key(self.model, self.c, self.classes, self.h, self.w, self.measure, self.seed)
+
+
+def init_distributed(args):
     import torch
     import torch.distributed as dist
-
-    import semanticsegmentationactivelearning_amd as ssal
-    from semanticsegmentationactivelearning_amd import _lib, active_learning as al, synthetic as syn
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -164,16 +412,54 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            if backend == "gloo":
-                dist.init_process_group("gloo")
-            else:
-                dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
-            dist.barrier()
-            torch.cuda.synchronize()
+            # a rank that never shows up: the rendezvous raises after --dist-timeout (-> non-zero exit); a rank that
+            # hangs later is caught by the Watchdog around every barrier / timed region
+            tmo = datetime.timedelta(seconds=args.dist_timeout)
+            with Watchdog(args.dist_timeout + 30.0, "init_process_group + first barrier"):
+                if backend == "gloo":
+                    dist.init_process_group("gloo", timeout=tmo)
+                else:
+                    dist.init_process_group("nccl", device_id=dev, timeout=tmo)  # nccl == RCCL on ROCm
+                dist.barrier()
+                torch.cuda.synchronize()
         finally:
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
+    return {"world": world, "rank": rank, "dev": dev, "backend": backend, "use_dist": use_dist}
+
+
+def secondary_leg(args, ctx, name, model, classes, c, measure, seed, note):
+    """a short N = 1 leg of another BASELINE config: value, ms_per_step, roofline, roofline_all, digest"""
+    import torch
+    steps, warm = max(1, args.secondary_steps), 2
+    leg = Leg(args, ctx, model, classes, c, measure, seed)
+    leg.make_resident(steps + warm)
+    i0, s0, _ = leg.run_steps(warm, 0)
+    leg.merge_and_select(i0, s0, warm)
+    torch.cuda.synchronize()
+    r = leg.timed(steps, warm, "secondary %s" % name)
+    out = {"config": note, "value": r["frames"] / r["elapsed"], "unit": "images/s", "steps": steps, "warmup": warm,
+           "ms_per_step": 1e3 * r["elapsed"] / steps, "dtype": "f32", "data": "synthetic",
+           "score_digest": score_digest(r["index"], r["score"], leg.key())}
+    if not args.no_roofline:
+        out["roofline"], out["roofline_all"] = roofline_leg(leg.net, leg.batches[0][0], measure, model)
+    del leg
+    torch.cuda.empty_cache()
+    return out
+
+
+def main(argv=None):
+    args = parse(argv)
+    import torch
+    import torch.distributed as dist
+
+    import semanticsegmentationactivelearning_amd as ssal
+    from semanticsegmentationactivelearning_amd import _lib, synthetic as syn
+
+    ctx = init_distributed(args)
+    world, rank, use_dist = ctx["world"], ctx["rank"], ctx["use_dist"]
+    scaling = args.scaling or ("strong" if world > 1 else "weak")
 
     knobs = _lib.get_knobs()
     if not knobs["defaults"] and not args.allow_nondefault_knobs:
@@ -182,153 +468,92 @@ def main():
     h, w, c, bs = args.height, args.width, args.channels, args.batch
     if args.measure is None:
         args.measure = "margin" if args.model == "icnet" else "entropy"
-    if args.model == "icnet":
-        net = ssal.ICNet(args.classes)
-        net.build((None, None, None, c))
-        syn.randomize_icnet(net, seed=0)
-    else:
-        net = ssal.ENet(args.classes)
-        net.build((None, None, None, c))
-        syn.randomize_enet(net, seed=0)
+    leg = Leg(args, ctx, args.model, args.classes, c, args.measure, args.weights_seed, args.input_dtype)
     model_name = "ICNet" if args.model == "icnet" else "ENet"
 
-    # ---- this rank's shard of the pool, device-resident before the clock starts -------------------
-    positions = al.shard_positions(POOL, rank, world)
-    positions = positions[positions >= 0]
-    n_batches_shard = (len(positions) + bs - 1) // bs
-    in_dtype = torch.uint8 if args.input_dtype == "u8" else torch.float32
-    bytes_per_batch = bs * h * w * c * (1 if args.input_dtype == "u8" else 4)
-    max_resident = max(1, int(args.resident_gib * 2 ** 30 // bytes_per_batch))
-    if args.scaling == "strong":
-        # total work fixed: this rank scores its whole shard of the 2975-frame pool, once
-        args.steps = n_batches_shard
-        args.warmup = min(args.warmup, 2)
-    need = min(args.steps + args.warmup, n_batches_shard)
-    n_resident = min(need, max_resident)
-    batches = []
-    for b in range(n_resident):
-        ids = positions[b * bs:(b + 1) * bs]
-        buf = torch.empty((len(ids), h, w, c), dtype=in_dtype, device=dev)
-        # strided shard: frame ids are not consecutive when world > 1 -> one generator call per frame
-        if world == 1:
-            syn.synth_frames_device(int(ids[0]), len(ids), h, w, c, out=buf)
-        else:
-            for j, f in enumerate(ids):
-                syn.synth_frames_device(int(f), 1, h, w, c, out=buf[j:j + 1])
-        batches.append((buf, torch.as_tensor(ids, device=dev)))
-    torch.cuda.synchronize()
+    # every rank derives the SAME step counts from the common padded shard length (ceil(POOL / world) frames):
+    # shards differ by at most one frame, but ceil(len / batch) of the long and the short shard can differ
+    per_rank = (POOL + world - 1) // world
+    strong_steps = (per_rank + bs - 1) // bs
+    requested_steps, warmup = args.steps, args.warmup
+    need = max(strong_steps if (scaling == "strong" or world > 1) else 0, args.steps + warmup)
+    n_resident = leg.make_resident(need)
     log("%d resident batches of %d frames (%.1f GiB) generated on device" %
-        (n_resident, bs, n_resident * bytes_per_batch / 2 ** 30))
-
-    def run_steps(k, first):
-        idx_chunks, score_chunks, frames = [], [], 0
-        for s in range(k):
-            xb, ib = batches[(first + s) % n_resident]
-            score_chunks.append(net.score(xb, measure=args.measure))
-            idx_chunks.append(ib)
-            frames += xb.shape[0]
-        return torch.cat(idx_chunks), torch.cat(score_chunks), frames
-
-    def merge_and_select(index, score):
-        # ONE collective: every rank ran the same number of steps, so each pads its (index, score) shard locally
-        # to steps * batch entries (a shard's last batch may be short) and all-gathers it
-        if use_dist:
-            index, score = al.pad_to_length(index, score, max(args.steps, args.warmup, 1) * bs)
-        all_index, all_score = al.all_gather_scores(index, score)
-        return al.finish_ranking(all_index.cpu().numpy(), all_score.cpu().numpy(), POOL,
-                                 np.arange(POOL), TOP_K)
+        (n_resident, bs, n_resident * leg.bytes_per_batch / 2 ** 30))
 
     # ---- warm-up (untimed) ------------------------------------------------------------------------
-    i0, s0, _ = run_steps(max(args.warmup, 1), 0)
-    merge_and_select(i0, s0)
-    torch.cuda.synchronize()
+    with Watchdog(args.dist_timeout + 120.0, "warm-up"):
+        i0, s0, _ = leg.run_steps(max(warmup, 1), 0)
+        leg.merge_and_select(i0, s0, max(warmup, 1))
+        torch.cuda.synchronize()
     log("warm-up done")
 
-    # ---- timed region: exactly --steps steps, barrier + synchronize on both sides -----------------
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    index, score, frames = run_steps(args.steps, 0 if args.scaling == "strong" else args.warmup)
-    low, _ = merge_and_select(index, score)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    log("timed region: %d steps in %.3f s on this rank" % (args.steps, elapsed))
-    t = torch.tensor([elapsed, float(frames)], dtype=torch.float64, device="cpu" if backend == "gloo" else dev)
-    if use_dist:
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        elapsed = float(tmax[0])
-        total_frames = float(t[1])
-    else:
-        total_frames = float(frames)
+    # ---- timed regions ----------------------------------------------------------------------------
+    weak = strong = None
+    if scaling == "strong" or world > 1:
+        # total work fixed: each rank scores its whole shard of the 2975-frame pool once (a short shard's missing
+        # last batch wraps onto batch 0 so that every rank issues the same number of steps; the duplicate is
+        # dropped by the scatter-by-index, which writes the same bits twice)
+        strong = leg.timed(strong_steps, 0, "strong (pool / %d ranks)" % world)
+    if scaling == "weak" or world > 1:
+        weak = leg.timed(requested_steps, warmup, "weak (%d steps per rank)" % requested_steps)
+    head = strong if scaling == "strong" else weak
 
     result = None
     if rank == 0:
-        value = total_frames / elapsed
+        frames_head = float(POOL) if scaling == "strong" else head["frames"]
+        value = frames_head / head["elapsed"]
+        metric = "unlabelled-pool images/sec scored (%s, %dx%d)" % (model_name, h, w)
+        workload = "%s pool of %d synthetic %dx%dx%d frames, %s acquisition, batch %d, K=%d, top-%d select%s" % (
+            ("configs[3]: ICNet multi-scale (1/4, 1/2, 1; %s)" % ICNET_NOTE) if args.model == "icnet"
+            else "configs[1]: ENet", POOL, h, w, c, args.measure, bs, args.classes, TOP_K,
+            ", uint8 resident frames" if args.input_dtype == "u8" else "")
+        if args.model == "icnet":
+            metric += " [%s]" % ICNET_NOTE
         result = {
-            "metric": "unlabelled-pool images/sec scored (%s, %dx%d)" % (model_name, h, w),
-            "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "metric": metric, "value": value, "unit": "images/s", "n_gpus": world, "steps": head["steps"],
+            "warmup": warmup, "ms_per_step": 1e3 * head["elapsed"] / head["steps"],
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s pool of %d synthetic %dx%dx%d frames, %s acquisition, "
-                                   "batch %d, K=%d, top-%d select%s" % ("configs[3]: ICNet multi-scale (1/4, 1/2, 1; ICNET_SPEC.md)"
-                                                                        if args.model == "icnet" else "configs[1]: ENet",
-                                                                        POOL, h, w, c, args.measure, bs, args.classes, TOP_K,
-                                                                        ", uint8 resident frames" if args.input_dtype == "u8" else ""),
-                       "frames_scored": int(total_frames), "resident_batches_per_rank": n_resident,
+            "config": {"workload": workload, "frames_scored": int(frames_head),
+                       "resident_batches_per_rank": n_resident,
                        "sharding": "strided pool shard per rank, one all-gather of (index, score)"},
+            "requested_steps": requested_steps,
             "knobs": knobs,
         }
+        if world > 1:
+            other = weak if scaling == "strong" else strong
+            oname = "weak" if scaling == "strong" else "strong"
+            oframes = other["frames"] if oname == "weak" else float(POOL)
+            result[oname] = {"value": oframes / other["elapsed"], "unit": "images/s", "steps": other["steps"],
+                             "ms_per_step": 1e3 * other["elapsed"] / other["steps"], "frames_scored": int(oframes),
+                             "scaling": oname}
+        # result check: digest of the scores of the frames the timed region scored vs the committed table
+        result["score_digest"] = score_digest(head["index"], head["score"], leg.key())
+        whole_pool = len(np.unique(head["index"][head["index"] >= 0])) >= POOL
+        result["top_k_checksum"] = int(np.sort(head["low"]).astype(np.int64).sum()) if whole_pool else None
 
-    # ---- roofline leg: per-kernel HIP-event timing of one extra batch (rank 0, outside the clock) --
+    # ---- roofline leg: per-kernel HIP-event timing of extra batches (rank 0, outside the clock) ----
     if rank == 0 and not args.no_roofline:
-        _lib.profile_enable(True)
-        reps = 3
-        for _ in range(reps):
-            net.score(batches[0][0], measure=args.measure)
-        torch.cuda.synchronize()
-        prof = _lib.profile_collect()
-        _lib.profile_enable(False)
+        result["roofline"], result["roofline_all"] = roofline_leg(leg.net, leg.batches[0][0], args.measure, args.model)
         log("roofline leg done")
-        dom = max(prof, key=lambda k: prof[k]["ms"])
-        d = prof[dom]
-        sec = d["ms"] * 1e-3
-        ai = d["flops"] / d["bytes"]
-        ridge = FP32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
-        if ai >= ridge:
-            bound, achieved, peak, unit = "mfma", d["flops"] / sec / 1e12, FP32_PEAK_TFLOPS, "TFLOP/s"
-        else:
-            bound, achieved, peak, unit = "hbm", d["bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s"
-        total_ms = sum(v["ms"] for v in prof.values())
-        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-        # (tools/gpu_pmc.sh + tools/pmc_summary.py: separate --pmc runs; (2*FETCH_SIZE + WRITE_SIZE)*1024,
-        # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); null if not collected
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc", "traffic_%s.json" % args.model)))
-            traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            pass
-        result["roofline"] = {
-            "kernel": dom, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
-            "frac": achieved / peak, "traffic": traffic,
-            "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
-            "algorithmic_flops_per_launch": d["flops"] / d["launches"],
-            "avg_launch_us": 1e3 * d["ms"] / d["launches"], "launches_per_batch": d["launches"] // reps,
-            "share_of_gpu_time": d["ms"] / total_ms,
-            "arithmetic_intensity_flop_per_byte": ai,
-            "achieved_tflops": d["flops"] / sec / 1e12, "achieved_gbs": d["bytes"] / sec / 1e9,
-            "per_kernel_ms_per_batch": {k: v["ms"] / reps for k, v in sorted(prof.items())},
+
+    # ---- the other single-GPU BASELINE configs (rank 0, N = 1 only) ---------------------------------
+    if rank == 0 and world == 1 and not args.no_secondary and args.model == "enet" and (h, w) == (1024, 2048):
+        leg.batches = leg.batches[:1]  # free the resident pool shard (keeps the roofline batch)
+        torch.cuda.empty_cache()
+        result["secondary"] = {
+            "c4": secondary_leg(args, ctx, "c4", "icnet", 19, 3, "margin", 0,
+                                "configs[3]: ICNet multi-scale (1/4, 1/2, 1), 1024x2048x3, K=19, margin; " + ICNET_NOTE),
+            "c5": secondary_leg(args, ctx, "c5", "enet", 6, 4, "entropy", 1,
+                                "configs[4]: ENet Freiburg-Forest shaped (RGB+NIR, 4-channel input), 1024x2048x4, K=6, "
+                                "entropy"),
         }
+        log("secondary legs done")
 
     # ---- CPU baseline leg (rank 0, N=1 only) ------------------------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        P = syn.enet_params_dict(net)
+        P = syn.enet_params_dict(leg.net)
         c1 = None
         if args.model == "enet":
             net1 = ssal.ENet(19)
@@ -338,16 +563,25 @@ def main():
         result["cpu_baseline"] = cpu_baseline(P, h, w, c, args.measure, args.cpu_seconds, c1=c1, model=args.model)
         result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
 
+    rc = 0
     if rank == 0:
-        # only meaningful when the whole pool was scored (default --steps 372 at N=1, or --scaling strong)
-        # (and no resident batch was scored twice: --resident-gib did not make the batch list wrap around)
-        whole_pool = int(total_frames) >= POOL and n_resident >= min(args.steps, n_batches_shard)
-        result["top_k_checksum"] = int(np.sort(low).astype(np.int64).sum()) if whole_pool else None
+        digests = [("headline", result["score_digest"])]
+        for nm, sec in result.get("secondary", {}).items():
+            digests.append((nm, sec["score_digest"]))
+        bad = [nm for nm, dg in digests if dg["match"] is False]
+        result["score_digest_verdict"] = ("MISMATCH: " + ", ".join(bad)) if bad else (
+            "ok" if all(dg["match"] for _, dg in digests) else "ok (no committed table entry for: %s)"
+            % ", ".join(nm for nm, dg in digests if dg["match"] is None))
         print(json.dumps(result), flush=True)
+        if bad and not args.allow_digest_mismatch:
+            log("score digest MISMATCH (%s): the timed kernels did not produce the committed scores" % ", ".join(bad))
+            rc = 4
     if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+        with Watchdog(args.dist_timeout, "final barrier"):
+            dist.barrier()
+            dist.destroy_process_group()
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

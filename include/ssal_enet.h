@@ -185,10 +185,6 @@ int ssal_set_kernel_family(int use_mfma);
  * semantics): writes 256 floats */
 int ssal_debug_probe(float *out_dev_256, void *stream);
 
-/* measurement aid: bare fp32 MFMA loop (shape 32 = 32x32x2, 16 = 16x16x4), 4 waves per block, 4
- * independent accumulators per wave; out_dev needs blocks*256 floats.  Time it with ssal_profile_*. */
-int ssal_debug_mfma_peak(int shape, int blocks, int iters, float *out_dev, void *stream);
-
 /* tuning / A-B knob of the fused bottleneck launchers ("bnk_tw": 16 forces 8x16 tiles, "bnk_xcd": 0 switches the
  * XCD-aware tile order off).  Every setting produces bit-identical results (tests/test_gpu_parity.py); SSAL_EINVAL for
  * an unknown name.  The product build reads no environment variable and contains no work-skipping switch: phase
@@ -199,12 +195,6 @@ int ssal_debug_set_knob(const char *name, int value);
  * bnk_xcd, ablate, measure_build, profiling, defaults (1 iff all are at their shipping values).  bench.py prints it
  * in its result line and refuses to time anything else. */
 int ssal_debug_get_knobs(char *json_out, int64_t cap);
-
-/* measurement aid (tools/mem_probe.py): y = x for an [n,h,w,64] tensor with the access shape `mode`
- * (0 linear, 1 MFMA-fragment tile, 2 coalesced tile, 3/4 = 1/2 + halo-ring reads, 5-8 other tile shapes, 9 group by group, 10-13 linear with 16 / 16 / 4 / 2 float4 per thread, 14 = 10 in slab order, 15-18 persistent workgroups that prefetch the next tile); h % 8 == 0, w % 32 == 0;
- * spin = shader clocks of ALU work between the loads and the stores. */
-int ssal_debug_copy_probe(int mode, const float *x_dev, float *y_dev, int n, int h, int w, int spin,
-                          void *stream);
 
 /* measurement aid, only functional in a -DSSAL_PHASE_TRACE build (tools/phase_trace.py; SSAL_ENOTIMPL
  * otherwise): the fused bottleneck kernels write 16 x uint64 per wave (shader-clock phase marks,

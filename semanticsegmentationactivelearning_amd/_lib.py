@@ -54,11 +54,9 @@ PROTOTYPES = {
     "ssal_synth_frames_nhwc_u8": (_i, [_c.c_uint64, _i64, _i, _i, _i, _i, _vp, _vp]),
     "ssal_set_kernel_family": (_i, [_i]),
     "ssal_debug_probe": (_i, [_vp, _vp]),
-    "ssal_debug_mfma_peak": (_i, [_i, _i, _i, _vp, _vp]),
     "ssal_debug_set_trace": (_i, [_vp, _i64]),
     "ssal_debug_set_knob": (_i, [ctypes.c_char_p, _i]),
     "ssal_debug_get_knobs": (_i, [_c.c_char_p, _i64]),
-    "ssal_debug_copy_probe": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
     # ---- include/ssal_icnet.h ----
     "ssal_icnet_create": (_i, [_i, _i, _c.POINTER(_vp)]),
     "ssal_icnet_destroy": (_i, [_vp]),
@@ -86,6 +84,12 @@ PROTOTYPES = {
     "ssal_profile_collect": (_i, [_c.c_char_p, _i64]),
 }
 
+# extra entry points of the measurement libraries only (csrc/ssal_measure_api.h; tools/mem_probe.py, tools/mfma_peak.py)
+MEASURE_PROTOTYPES = {
+    "ssal_debug_mfma_peak": (_i, [_i, _i, _i, _vp, _vp]),
+    "ssal_debug_copy_probe": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
+}
+
 _LIB = None
 
 
@@ -107,6 +111,11 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        for name, (res, args) in MEASURE_PROTOTYPES.items():
+            fn = getattr(handle, name, None)  # present in -DSSAL_MEASURE builds only
+            if fn is not None:
+                fn.restype = res
+                fn.argtypes = args
         _LIB = handle
     return _LIB
 

@@ -146,9 +146,10 @@ def prefetch_to_device(batches, depth=2):
             dev = host.cuda(non_blocking=True)
             done = torch.cuda.Event()
             done.record(copy_stream)
-        issued = getattr(images, "_ssal_copy_issued", None)
-        if issued is not None:
-            issued(done)  # page-locked ring slot of tensortools.input.InputStage: not rewritten before `done`
+        # page-locked ring slot of a tensortools.input.InputStage (found by the address of the batch's memory, so
+        # sliced / re-wrapped batches resolve too): the stage does not rewrite it before `done`
+        from .tensortools import input as _input
+        _input.copy_issued(host, done)
         return dev, indices, done, host  # the host buffer must outlive the copy
 
     def release(entry):
@@ -194,8 +195,9 @@ def rank_confidence(net, batches, num_examples, unlabelled, selection_size, meas
 
     Collectives per ranking pass: exactly ONE all-gather of ``(index, score)`` pairs.  Shards handed out by
     ``shard_positions`` hold at most ``ceil(num_examples / world)`` examples, so each rank pads locally to that
-    length.  ``ragged=True`` is for callers that split the pool some other way (shard lengths unknown to the
-    other ranks): it costs one extra all-reduce(MAX) to agree on the length."""
+    length (+ one flag entry).  A rank whose shard is longer raises ``ValueError`` -- on EVERY rank, after the
+    collective, so nobody is left blocking in it.  ``ragged=True`` is for callers that split the pool some other way
+    (shard lengths unknown to the other ranks): it costs one extra all-reduce(MAX) to agree on the length."""
     torch = _lib.require_gpu()
     idx_chunks, score_chunks = [], []
     if prefetch > 0:
@@ -218,14 +220,32 @@ def merge_and_rank(local_index, local_score, num_examples, unlabelled, selection
     """the collective + host tail of a ranking pass (shared by ``rank_confidence`` and ``bench.py``)"""
     import torch.distributed as dist
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    overflow = False
     if world > 1:
         if ragged:
             local_index, local_score = _pad_to_common_length(local_index, local_score, group)
         else:
-            local_index, local_score = pad_to_length(local_index, local_score, (num_examples + world - 1) // world)
+            # precondition: len(shard) <= ceil(num_examples / world) (what shard_positions hands out).  A rank that
+            # violates it must not raise BEFORE the collective (the others would block in the all-gather until the
+            # backend times out): it contributes an all-sentinel shard of the agreed length whose extra last entry
+            # carries the flag (index -1, score -inf; +inf = fine), and EVERY rank raises after the collective.
+            per = (num_examples + world - 1) // world
+            overflow = local_index.numel() > per
+            if overflow:
+                local_index, local_score = local_index[:0], local_score[:0]
+            local_index, local_score = pad_to_length(local_index, local_score, per + 1)
+            if overflow:
+                local_score = local_score.clone()
+                local_score[-1] = float("-inf")
     all_index, all_score = all_gather_scores(local_index, local_score, group)
-    return finish_ranking(all_index.cpu().numpy(), all_score.cpu().numpy(), num_examples,
-                          unlabelled, selection_size)
+    all_index, all_score = all_index.cpu().numpy(), all_score.cpu().numpy()
+    if world > 1 and not ragged:
+        bad = np.nonzero((all_index < 0) & np.isneginf(all_score))[0]
+        if len(bad):
+            raise ValueError("rank(s) %s handed merge_and_rank a shard longer than ceil(num_examples / world) = %d "
+                             "entries; split the pool with shard_positions() or pass ragged=True"
+                             % (sorted(set((bad // (per + 1)).tolist())), per))
+    return finish_ranking(all_index, all_score, num_examples, unlabelled, selection_size)
 
 
 def _pad_to_common_length(index, score, group):

@@ -20,8 +20,13 @@ CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=
 FLAGS = CFLAGS + ["-shared"]  # one-shot form (tools/phase_trace.py builds its measurement variant with it)
 
 
-def sources():
-    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+MEASURE_ONLY = ("ssal_probe.hip",)  # copy / MFMA probes: measurement libraries only (tools/phase_trace.py)
+
+
+def sources(measure=False):
+    """product sources; measure=True adds the probe kernels of the -DSSAL_MEASURE libraries"""
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)
+                  if f.endswith(".hip") and (measure or f not in MEASURE_ONLY))
 
 
 def _headers():

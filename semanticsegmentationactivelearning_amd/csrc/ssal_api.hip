@@ -1111,6 +1111,7 @@ SSAL_API int ssal_debug_probe(float *out_dev_256, void *stream)
     return SSAL_OK;
 }
 
+#ifdef SSAL_MEASURE  // measurement library only (csrc/ssal_measure_api.h)
 SSAL_API int ssal_debug_mfma_peak(int shape, int blocks, int iters, float *out_dev, void *stream)
 {
     if (!out_dev || blocks <= 0 || iters <= 0 || (shape != 32 && shape != 16 && shape != 132 && shape != 232 && shape != 332 && shape != 432))
@@ -1118,6 +1119,7 @@ SSAL_API int ssal_debug_mfma_peak(int shape, int blocks, int iters, float *out_d
     HIP_TRY(launch_mfma_peak(shape, blocks, iters, out_dev, (hipStream_t)stream));
     return SSAL_OK;
 }
+#endif
 
 SSAL_API int ssal_debug_set_knob(const char *name, int value)
 {
@@ -1152,6 +1154,7 @@ SSAL_API int ssal_debug_get_knobs(char *json_out, int64_t cap)
     return SSAL_OK;
 }
 
+#ifdef SSAL_MEASURE  // measurement library only (csrc/ssal_measure_api.h)
 SSAL_API int ssal_debug_copy_probe(int mode, const float *x_dev, float *y_dev, int n, int h, int w, int spin,
                                    void *stream)
 {
@@ -1159,6 +1162,7 @@ SSAL_API int ssal_debug_copy_probe(int mode, const float *x_dev, float *y_dev, i
     HIP_TRY(launch_copy_probe(mode, x_dev, y_dev, n, h, w, spin, (hipStream_t)stream));
     return SSAL_OK;
 }
+#endif
 
 SSAL_API int ssal_debug_set_trace(void *buf_dev, int64_t bytes)
 {

@@ -29,7 +29,8 @@ struct BnkArgs {
     int ntiles, xcd_chunk;  // XCD-aware tile order: tile = (b % 8) * xcd_chunk + b / 8 (xcd_chunk = 0: tile = b)
 #ifdef SSAL_MEASURE
     int ablate;            // measurement builds only (tools/phase_trace.py): 1 = stop after the projection phase,
-                           // 2 = skip the projection phase (results invalid; timing only)
+                           // 2 = skip the projection phase, 3 = no residual traffic, 4 = no store traffic, 5 = 3 + 4,
+                           // 6 = projection loads all hit pixel 0, 7 = 5 + 6  (results invalid; timing only)
 #endif
 };
 

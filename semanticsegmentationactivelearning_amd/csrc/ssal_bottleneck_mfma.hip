@@ -84,6 +84,7 @@ __device__ __forceinline__ void proj_to_lds(const Args &a, const float *ximg, fl
             continue;
         }
         const float *xp = valid ? ximg + ((long)(py + pr * d) * a.W + (px + pc * d)) * C : ximg;
+        if (SSAL_ABLATE_IS(a, 6) || SSAL_ABLATE_IS(a, 7)) xp = ximg;  // timing only: every lane reads pixel 0 (cache hits)
         // all 16 activation fragments of the M-tile are requested before the first MFMA (the compiler
         // would otherwise serialise load-pair / wait / 8 MFMAs and expose the memory latency 8 times)
         float4 X[16];
@@ -268,8 +269,12 @@ __device__ __forceinline__ void conv_exp_store(const BnkArgs &a, const float *xi
     // offset the range check always rejects, even after the +384 B N-tile immediates
     constexpr unsigned kOOB = 0x80000000u;
     const unsigned img_bytes = (unsigned)(a.H * a.W * C) * 4u;
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ximg), 0, img_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yimg, 0, img_bytes, 0x00020000);
+    // measurement builds (timing only, results invalid): ablate 3 / 5 / 7 give the residual resource zero records (every
+    // load is answered with 0 by the range check, no memory traffic), 4 / 5 / 7 the output resource (stores dropped)
+    const unsigned xbytes = (SSAL_ABLATE_IS(a, 3) || SSAL_ABLATE_IS(a, 5) || SSAL_ABLATE_IS(a, 7)) ? 0u : img_bytes;
+    const unsigned ybytes = (SSAL_ABLATE_IS(a, 4) || SSAL_ABLATE_IS(a, 5) || SSAL_ABLATE_IS(a, 7)) ? 0u : img_bytes;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ximg), 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yimg, 0, ybytes, 0x00020000);
     const rsrc_t wers = make_rsrc(a.we, F * C * 4), esrs = make_rsrc(a.es, C * 4), etrs = make_rsrc(a.et, C * 4),
                  rars = make_rsrc(a.ra, C * 4);
     const unsigned welo = (unsigned)(h * C + j) * 4u;
@@ -994,86 +999,6 @@ __global__ void k_probe_swap(float *out)
     swap16(c, e);
     out[128 + threadIdx.x] = c;
     out[192 + threadIdx.x] = e;
-}
-
-// ---- measurement aid: what the fp32 matrix pipe of THIS device sustains (bare dependent-free MFMA
-// loop, operands in registers, 4 accumulators per wave, 1 or 2 waves per SIMD) -------------------------
-// SHAPE 32 / 16: four independent accumulators; SHAPE 132: ONE dependent 32x32x2 chain per wave;
-// SHAPE 232: one dependent chain with a v_permlane32_swap feeding every MFMA pair (the conv loop shape)
-template <int SHAPE>
-__global__ __launch_bounds__(256) void k_mfma_peak(float *out, int iters)
-{
-    float a = 1.0f + 1e-3f * threadIdx.x, b = 0.999f;
-    if (SHAPE == 32) {
-        f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
-        for (int i = 0; i < iters; ++i) {
-            c0 = mfma32(a, b, c0); c1 = mfma32(a, b, c1); c2 = mfma32(a, b, c2); c3 = mfma32(a, b, c3);
-        }
-        out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
-    } else if (SHAPE == 132) {
-        f32x16 c0 = {0};
-        for (int i = 0; i < iters; ++i) {
-            c0 = mfma32(a, b, c0); c0 = mfma32(b, a, c0); c0 = mfma32(a, b, c0); c0 = mfma32(b, a, c0);
-        }
-        out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c0[5];
-    } else if (SHAPE == 332 || SHAPE == 432) {
-        // four independent accumulators + 8 (332) / 16 (432) independent v_fma_f32 per four MFMAs: does vector work of
-        // the same wave / of co-resident waves execute in the shadow of the matrix pipe, or does it add to it?
-        f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
-        float v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = a + k;
-        for (int i = 0; i < iters; ++i) {
-            c0 = mfma32(a, b, c0);
-#pragma unroll
-            for (int k = 0; k < (SHAPE == 432 ? 4 : 2); ++k) v[k] = fmaf(v[k], 1.0000001f, b);
-            c1 = mfma32(a, b, c1);
-#pragma unroll
-            for (int k = 0; k < (SHAPE == 432 ? 4 : 2); ++k) v[2 + k] = fmaf(v[2 + k], 1.0000001f, b);
-            c2 = mfma32(a, b, c2);
-#pragma unroll
-            for (int k = 0; k < (SHAPE == 432 ? 4 : 2); ++k) v[4 + (k & 3)] = fmaf(v[4 + (k & 3)], 1.0000001f, b);
-            c3 = mfma32(a, b, c3);
-#pragma unroll
-            for (int k = 0; k < (SHAPE == 432 ? 4 : 2); ++k) v[(6 + k) & 7] = fmaf(v[(6 + k) & 7], 1.0000001f, b);
-        }
-        float t = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t += v[k];
-        out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3] + t;
-    } else if (SHAPE == 232) {
-        f32x16 c0 = {0};
-        float p = a, q = b;
-        for (int i = 0; i < iters; ++i) {
-            swap32(p, q); c0 = mfma32(a, p, c0); c0 = mfma32(b, q, c0);
-            swap32(p, q); c0 = mfma32(a, p, c0); c0 = mfma32(b, q, c0);
-        }
-        out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c0[5];
-    } else {
-        f32x4 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
-        for (int i = 0; i < iters; ++i) {
-            c0 = mfma16(a, b, c0); c1 = mfma16(a, b, c1); c2 = mfma16(a, b, c2); c3 = mfma16(a, b, c3);
-        }
-        out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
-    }
-}
-
-hipError_t launch_mfma_peak(int shape, int blocks, int iters, float *out, hipStream_t s)
-{
-    const bool is32 = shape != 16;
-    const double flop = (double)blocks * 4 /*waves*/ * iters * 4.0 * (is32 ? 4096.0 : 2048.0);
-    const char *nm = shape == 32 ? "k_mfma_peak<32x32x2 4acc>" : shape == 132 ? "k_mfma_peak<32x32x2 1chain>"
-                   : shape == 232 ? "k_mfma_peak<32x32x2 1chain+swap>"
-                   : shape == 332 ? "k_mfma_peak<32x32x2 4acc + 8 v_fma / 4 mfma>"
-                   : shape == 432 ? "k_mfma_peak<32x32x2 4acc + 16 v_fma / 4 mfma>" : "k_mfma_peak<16x16x4 4acc>";
-    ProfScope prof(nm, flop, 0.0, s);
-    if (shape == 32) hipLaunchKernelGGL(k_mfma_peak<32>, dim3(blocks), dim3(256), 0, s, out, iters);
-    else if (shape == 132) hipLaunchKernelGGL(k_mfma_peak<132>, dim3(blocks), dim3(256), 0, s, out, iters);
-    else if (shape == 232) hipLaunchKernelGGL(k_mfma_peak<232>, dim3(blocks), dim3(256), 0, s, out, iters);
-    else if (shape == 332) hipLaunchKernelGGL(k_mfma_peak<332>, dim3(blocks), dim3(256), 0, s, out, iters);
-    else if (shape == 432) hipLaunchKernelGGL(k_mfma_peak<432>, dim3(blocks), dim3(256), 0, s, out, iters);
-    else hipLaunchKernelGGL(k_mfma_peak<16>, dim3(blocks), dim3(256), 0, s, out, iters);
-    return hipGetLastError();
 }
 
 Knobs &knobs()

@@ -18,7 +18,7 @@ __device__ __forceinline__ uint64_t splitmix64_x(uint64_t z)
 // xops.spatial_dropout (models/util/extra_ops.py:137-151): tf.nn.dropout(x, rate, noise_shape=[N,1,1,C]).
 // TF-1.13 dropout: keep_prob = 1 - rate; binary = floor(keep_prob + uniform[0,1)); y = (x / keep_prob) * binary,
 // with ONE uniform draw per (image, channel) plane.  The draw here is a counter-based hash of (seed, n*C + c)
-// (host twin: models/util/extra_ops.spatial_dropout_keep_mask) -- TensorFlow's own random stream cannot be
+// (restated for the tests in oracle/dropout_oracle.py) -- TensorFlow's own random stream cannot be
 // reproduced, the distribution and the arithmetic are.
 // One float4 (4 consecutive channels of one pixel) per thread per step: coalesced NHWC, HBM-bound
 // (4 B in + 4 B out per element).

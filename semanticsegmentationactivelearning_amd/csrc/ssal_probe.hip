@@ -1,7 +1,10 @@
-// ssal_probe.hip -- memory-pattern probes (measurement aid, tools/mem_probe.py): y = x for an NHWC
+// ssal_probe.hip -- MEASUREMENT LIBRARY ONLY (libssal_hip_measure.so / libssal_hip_trace.so, built by
+// tools/phase_trace.py with -DSSAL_MEASURE; build.py leaves this file out of the product libssal_hip.so).
+// Memory-pattern probes (tools/mem_probe.py) and bare fp32 MFMA loops (tools/mfma_peak.py): y = x for an NHWC
 // tensor with 64 channels, using the access shapes the fused kernels use, to find out what the memory
 // system sustains for each shape.  No product path calls these.
 #include "ssal_internal.h"
+#include "ssal_mfma.h"
 #include "ssal_prof.h"
 
 namespace ssal {
@@ -283,6 +286,86 @@ hipError_t launch_copy_probe(int mode, const float *x, float *y, int N, int H, i
     case 13: hipLaunchKernelGGL((k_probe_linear_u<2, true>), dim3((unsigned)((n / 4 + 511) / 512)), dim3(256), 0, s,
                                 (const float4 *)x, (float4 *)y, n / 4); break;
     }
+    return hipGetLastError();
+}
+
+// ---- measurement aid: what the fp32 matrix pipe of THIS device sustains (bare dependent-free MFMA
+// loop, operands in registers, 4 accumulators per wave, 1 or 2 waves per SIMD) -------------------------
+// SHAPE 32 / 16: four independent accumulators; SHAPE 132: ONE dependent 32x32x2 chain per wave;
+// SHAPE 232: one dependent chain with a v_permlane32_swap feeding every MFMA pair (the conv loop shape)
+template <int SHAPE>
+__global__ __launch_bounds__(256) void k_mfma_peak(float *out, int iters)
+{
+    float a = 1.0f + 1e-3f * threadIdx.x, b = 0.999f;
+    if (SHAPE == 32) {
+        f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+        for (int i = 0; i < iters; ++i) {
+            c0 = mfma32(a, b, c0); c1 = mfma32(a, b, c1); c2 = mfma32(a, b, c2); c3 = mfma32(a, b, c3);
+        }
+        out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
+    } else if (SHAPE == 132) {
+        f32x16 c0 = {0};
+        for (int i = 0; i < iters; ++i) {
+            c0 = mfma32(a, b, c0); c0 = mfma32(b, a, c0); c0 = mfma32(a, b, c0); c0 = mfma32(b, a, c0);
+        }
+        out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c0[5];
+    } else if (SHAPE == 332 || SHAPE == 432) {
+        // four independent accumulators + 8 (332) / 16 (432) independent v_fma_f32 per four MFMAs: does vector work of
+        // the same wave / of co-resident waves execute in the shadow of the matrix pipe, or does it add to it?
+        f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = a + k;
+        for (int i = 0; i < iters; ++i) {
+            c0 = mfma32(a, b, c0);
+#pragma unroll
+            for (int k = 0; k < (SHAPE == 432 ? 4 : 2); ++k) v[k] = fmaf(v[k], 1.0000001f, b);
+            c1 = mfma32(a, b, c1);
+#pragma unroll
+            for (int k = 0; k < (SHAPE == 432 ? 4 : 2); ++k) v[2 + k] = fmaf(v[2 + k], 1.0000001f, b);
+            c2 = mfma32(a, b, c2);
+#pragma unroll
+            for (int k = 0; k < (SHAPE == 432 ? 4 : 2); ++k) v[4 + (k & 3)] = fmaf(v[4 + (k & 3)], 1.0000001f, b);
+            c3 = mfma32(a, b, c3);
+#pragma unroll
+            for (int k = 0; k < (SHAPE == 432 ? 4 : 2); ++k) v[(6 + k) & 7] = fmaf(v[(6 + k) & 7], 1.0000001f, b);
+        }
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += v[k];
+        out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3] + t;
+    } else if (SHAPE == 232) {
+        f32x16 c0 = {0};
+        float p = a, q = b;
+        for (int i = 0; i < iters; ++i) {
+            swap32(p, q); c0 = mfma32(a, p, c0); c0 = mfma32(b, q, c0);
+            swap32(p, q); c0 = mfma32(a, p, c0); c0 = mfma32(b, q, c0);
+        }
+        out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c0[5];
+    } else {
+        f32x4 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+        for (int i = 0; i < iters; ++i) {
+            c0 = mfma16(a, b, c0); c1 = mfma16(a, b, c1); c2 = mfma16(a, b, c2); c3 = mfma16(a, b, c3);
+        }
+        out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
+    }
+}
+
+hipError_t launch_mfma_peak(int shape, int blocks, int iters, float *out, hipStream_t s)
+{
+    const bool is32 = shape != 16;
+    const double flop = (double)blocks * 4 /*waves*/ * iters * 4.0 * (is32 ? 4096.0 : 2048.0);
+    const char *nm = shape == 32 ? "k_mfma_peak<32x32x2 4acc>" : shape == 132 ? "k_mfma_peak<32x32x2 1chain>"
+                   : shape == 232 ? "k_mfma_peak<32x32x2 1chain+swap>"
+                   : shape == 332 ? "k_mfma_peak<32x32x2 4acc + 8 v_fma / 4 mfma>"
+                   : shape == 432 ? "k_mfma_peak<32x32x2 4acc + 16 v_fma / 4 mfma>" : "k_mfma_peak<16x16x4 4acc>";
+    ProfScope prof(nm, flop, 0.0, s);
+    if (shape == 32) hipLaunchKernelGGL(k_mfma_peak<32>, dim3(blocks), dim3(256), 0, s, out, iters);
+    else if (shape == 132) hipLaunchKernelGGL(k_mfma_peak<132>, dim3(blocks), dim3(256), 0, s, out, iters);
+    else if (shape == 232) hipLaunchKernelGGL(k_mfma_peak<232>, dim3(blocks), dim3(256), 0, s, out, iters);
+    else if (shape == 332) hipLaunchKernelGGL(k_mfma_peak<332>, dim3(blocks), dim3(256), 0, s, out, iters);
+    else if (shape == 432) hipLaunchKernelGGL(k_mfma_peak<432>, dim3(blocks), dim3(256), 0, s, out, iters);
+    else hipLaunchKernelGGL(k_mfma_peak<16>, dim3(blocks), dim3(256), 0, s, out, iters);
     return hipGetLastError();
 }
 

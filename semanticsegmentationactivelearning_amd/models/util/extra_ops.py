@@ -53,24 +53,12 @@ def unpool_2d(inputs, idx, strides=[1, 2, 2, 1], name="Unpool2D", idx_has_batch=
     return y
 
 
-def spatial_dropout_keep_mask(n, c, drop_rate, seed=0):
-    """Host twin of the device draw: float32 [n, c] of 0/1, ``floor((1 - rate) + u[n, c])`` with ``u`` the
-    counter-based hash the kernel uses (splitmix64 of ``seed ^ (n*C + c) * K``, top 24 bits)."""
-    import numpy as np
-    from ...synthetic import _splitmix64
-    with np.errstate(over="ignore"):
-        idx = np.arange(n * c, dtype=np.uint64)
-        h = _splitmix64(np.uint64(seed) ^ (idx * np.uint64(0xD1342543DE82EF95)))
-    u = (h >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
-    keep_prob = np.float32(1.0) - np.float32(drop_rate)
-    return np.floor(keep_prob + u).astype(np.float32).reshape(n, c)
-
-
 def spatial_dropout(inputs, drop_rate, name="SpatialDropout", seed=0):
     """Channel-wise (whole feature-plane) dropout: ``tf.nn.dropout(inputs, rate, noise_shape=[N,1,1,C])``
     (reference extra_ops.py:137-151; used by the bottlenecks only when ``training`` -- enet_modules.py:591-594 --
     so it is the identity on the scoring path).  ``y = (x / (1 - rate)) * keep[n, c]``.  The keep draw is a seeded
-    counter-based hash (``spatial_dropout_keep_mask``); TensorFlow's own random stream cannot be reproduced."""
+    counter-based hash (splitmix64 of ``seed ^ (n*C + c) * K``, top 24 bits; restated for the tests in
+    ``oracle/dropout_oracle.py``); TensorFlow's own random stream cannot be reproduced."""
     torch = _lib.require_gpu()
     if not 0.0 <= float(drop_rate) < 1.0:
         raise ValueError("drop_rate must be in [0, 1)")

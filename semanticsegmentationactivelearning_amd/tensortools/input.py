@@ -24,6 +24,8 @@ import logging
 import os
 from concurrent.futures import ThreadPoolExecutor
 
+import weakref
+
 import numpy as np
 
 from . import tfrecord
@@ -60,6 +62,31 @@ class _Dataset:
     def __init__(self, filenames, aux, batch_size, augment, count):
         self.filenames, self.aux, self.batch_size, self.augment, self.count = \
             filenames, aux, batch_size, augment, count
+
+
+# page-locked ring slots of every live InputStage: base address -> (bytes, weakref(stage), slot)
+_PINNED_SLOTS = {}
+
+
+def copy_issued(tensor, event):
+    """Tell the InputStage that owns the page-locked memory behind ``tensor`` (a batch it yielded, or any slice / view /
+    re-wrapped copy-free alias of one) that an asynchronous host-to-device copy reading it has been issued and is
+    complete once ``event`` (a ``torch.cuda.Event``) has fired.  The stage waits for the event before it writes the next
+    batch into that slot.  Returns True if the memory belongs to a ring slot, False otherwise (pageable batches, arrays
+    the caller made itself): nothing to protect then."""
+    try:
+        ptr = int(tensor.data_ptr()) if hasattr(tensor, "data_ptr") else int(tensor.__array_interface__["data"][0])
+    except Exception:
+        return False
+    for base, (nbytes, stage_ref, slot) in list(_PINNED_SLOTS.items()):
+        if base <= ptr < base + nbytes:
+            stage = stage_ref()
+            if stage is None:
+                _PINNED_SLOTS.pop(base, None)
+                return False
+            stage._pin_events.setdefault(slot, []).append(event)
+            return True
+    return False
 
 
 class InputStage:
@@ -182,9 +209,10 @@ class InputStage:
     def _stack_pinned(self, images):
         """np.stack(images) written into the next buffer of the page-locked ring -> CPU torch tensor.
 
-        A consumer that copies the batch to the GPU asynchronously (``active_learning.prefetch_to_device``) hands
-        the copy-done event back through the tensor's ``_ssal_copy_issued`` hook; a slot is never rewritten on
-        the host while a DMA read of it is still in flight."""
+        A consumer that copies the batch to the GPU asynchronously (``active_learning.prefetch_to_device``) reports
+        the copy-done event through ``copy_issued(tensor, event)`` (module level, below), which finds the ring slot by
+        the ADDRESS of the tensor's memory -- slices, views, ``torch.as_tensor`` / numpy round trips of the batch all
+        resolve to their slot.  A slot is never rewritten on the host while a DMA read of it is still in flight."""
         import torch
         shape = (len(images),) + tuple(images[0].shape)
         dtype = torch.uint8 if images[0].dtype == np.uint8 else torch.float32
@@ -192,20 +220,22 @@ class InputStage:
         slot = self._pin_pos % self.pin_buffers
         self._pin_pos += 1
         if slot >= len(self._pinned):
-            self._pinned.append(torch.empty(need, dtype=dtype, pin_memory=True))
-        ev = self._pin_events.pop(slot, None)
-        if ev is not None:
+            self._pinned.append(None)
+        for ev in self._pin_events.pop(slot, ()):
             ev.synchronize()  # the previous batch in this slot has left for the GPU
-        if self._pinned[slot].numel() < need or self._pinned[slot].dtype != dtype:
+        if self._pinned[slot] is None or self._pinned[slot].numel() < need or self._pinned[slot].dtype != dtype:
+            if self._pinned[slot] is not None:
+                _PINNED_SLOTS.pop(self._pinned[slot].data_ptr(), None)
             self._pinned[slot] = torch.empty(need, dtype=dtype, pin_memory=True)
+            buf = self._pinned[slot]
+            _PINNED_SLOTS[buf.data_ptr()] = (buf.numel() * buf.element_size(), weakref.ref(self), slot)
         out = self._pinned[slot][:need].view(shape)
         np.stack(images, out=out.numpy())
-        events = self._pin_events
-
-        def _copy_issued(event, _slot=slot):
-            events[_slot] = event
-        out._ssal_copy_issued = _copy_issued
         return out
+
+    def copy_issued(self, tensor, event):
+        """see the module-level ``copy_issued``"""
+        return copy_issued(tensor, event)
 
     # ---- per-example work -------------------------------------------------------------------------
     def _load_one(self, filename, augment, seed):

@@ -30,3 +30,13 @@ def report_diff(name, got, want, exact=True, atol=0.0):
         d = np.abs(got.astype(np.float64) - want.astype(np.float64))
         raise AssertionError("%s: %d / %d elements differ (max |d| = %.3e, first at %s: got %r want %r)"
                              % (name, nbad, got.size, float(np.nanmax(d)), first, got[first], want[first]))
+
+
+def pool_score_table(model, c, classes, h, w, measure, seed):
+    """the committed per-frame float64 scores bench.py's `score_digest` is compared with (tests/golden/pool_scores.npz,
+    written by tools/make_pool_scores.py on an MI355X)"""
+    import os
+    import bench
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pool_scores.npz")
+    with np.load(path) as z:
+        return np.array(z[bench.table_key(model, c, classes, h, w, measure, seed)], dtype=np.float64)

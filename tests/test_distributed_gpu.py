@@ -100,3 +100,48 @@ def test_rccl_backend_executes_with_one_rank(tmp_path):
     executes on this machine -- the part the gloo rehearsals cannot reach."""
     mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
     assert open(tmp_path / "rccl_ok").read() == "1"
+
+
+def _run_bench(extra, nproc, tmp_path, tag):
+    import json
+    import subprocess
+    env = dict(os.environ, SSAL_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--height", "64", "--width", "128", "--warmup", "1", "--no-cpu-baseline", "--no-roofline", "--no-secondary"]
+    bench = os.path.join(ROOT, "bench.py")
+    if nproc == 1:
+        cmd = [sys.executable, bench, "--gpus", "1"] + common + extra
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), bench, "--gpus", str(nproc)] + common + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]  # stdout carries exactly ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_strong_scaling_end_to_end(tmp_path):
+    """`bench.py` launched exactly as the driver does it for N = 2 (torch.distributed.run, one process per
+    rank; here both ranks share the one GPU and the collectives run over gloo) defaults to STRONG scaling: the whole
+    2975-frame pool split over the ranks, the weak figure beside it, and the same top-128 selection / the same score digest
+    as a single-process pass over the pool (small frames, so the pass takes seconds)."""
+    two = _run_bench(["--steps", "5"], 2, tmp_path, "n2")
+    one = _run_bench(["--steps", "372"], 1, tmp_path, "n1")
+    assert two["scaling"] == "strong" and two["n_gpus"] == 2 and two["config"]["frames_scored"] == 2975
+    assert two["steps"] == 186 and two["requested_steps"] == 5  # ceil(ceil(2975 / 2) / 8)
+    assert two["weak"]["scaling"] == "weak" and two["weak"]["steps"] == 5 and two["weak"]["frames_scored"] == 2 * 5 * 8
+    assert one["scaling"] == "weak" and one["steps"] == 372 and one["config"]["frames_scored"] == 2975
+    assert two["top_k_checksum"] is not None and two["top_k_checksum"] == one["top_k_checksum"]
+    assert two["score_digest"]["frames"] == 2975 and two["score_digest"]["sha256"] == one["score_digest"]["sha256"]
+    assert two["score_digest"]["match"] is None  # no committed table for the small rehearsal frames
+
+
+def test_bench_missing_rank_exits_nonzero_instead_of_hanging(tmp_path):
+    """a rank that never arrives: the rendezvous times out and the process exits non-zero"""
+    import subprocess
+    env = dict(os.environ, SSAL_DIST_BACKEND="gloo", RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--height", "64", "--width", "128",
+                        "--dist-timeout", "8", "--no-cpu-baseline", "--no-roofline"], env=env, capture_output=True, timeout=120)
+    assert r.returncode != 0
+    assert b"{\"metric\"" not in r.stdout

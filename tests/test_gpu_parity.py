@@ -11,7 +11,7 @@ import pytest
 import torch
 
 import semanticsegmentationactivelearning_amd as ssal
-from helpers import frames, report_diff
+from helpers import frames, pool_score_table, report_diff
 from oracle import enet_oracle as orc
 from oracle import torch_restatement as tr
 from semanticsegmentationactivelearning_amd import _lib, active_learning as al, synthetic as syn
@@ -524,6 +524,42 @@ def test_full_resolution_image_bit_exact(enet_c3k19):
     want_mean, _, want_label = orc.score_logits(want, "entropy")
     report_diff("1024x2048 label", extra["label"].cpu().numpy(), want_label)
     report_diff("1024x2048 mean", scores.cpu().numpy(), want_mean, exact=False, atol=1e-6)
+    # the frame just checked against the oracle is entry 100 of the table bench.py's score_digest is compared with
+    table = pool_score_table("enet", 3, 19, 1024, 2048, "entropy", 0)
+    assert scores.cpu().numpy()[0] == table[100], "HIP score of frame 100 != committed pool_scores.npz entry"
+
+
+def test_full_resolution_c5_rgb_nir_frame_bit_exact(enet_c4k6):
+    """BASELINE configs[4] at its stated size: one 1024x2048x4 (RGB + NIR) frame, 6 classes (reference
+    datasets/freiburg.py:47, conf/freiburg_forest.json), entropy -- logits / labels bit-exact against the C oracle,
+    per-image mean <= 1e-6 (~20 s of CPU)"""
+    net, P = enet_c4k6
+    x = frames([100], 1024, 2048, 4)
+    want = orc.enet_forward(P, x, {})
+    xd = dev(x)
+    scores, extra = net.score(xd, "entropy", return_label=True)
+    got = net(xd, training=False).cpu().numpy()
+    assert got.shape == (1, 1024, 2048, 6)
+    report_diff("C5 1024x2048x4 logits (bit-exact)", got, want)
+    want_mean, _, want_label = orc.score_logits(want, "entropy")
+    report_diff("C5 1024x2048x4 label", extra["label"].cpu().numpy(), want_label)
+    report_diff("C5 1024x2048x4 mean", scores.cpu().numpy(), want_mean, exact=False, atol=1e-6)
+    table = pool_score_table("enet", 4, 6, 1024, 2048, "entropy", 1)
+    assert scores.cpu().numpy()[0] == table[100], "HIP score of C5 frame 100 != committed pool_scores.npz entry"
+
+
+def test_pool_score_table_entries_reproduce_in_other_batch_compositions(enet_c3k19):
+    """bench.py compares the SHA-256 of the scores it timed with the same frames of tests/golden/pool_scores.npz: entries of
+    that table must be reproduced bit for bit whatever batch a frame is scored in (batches of 3, 1 and 8 here; the table
+    was produced in batches of 8 starting at multiples of 8)"""
+    net, _ = enet_c3k19
+    table = pool_score_table("enet", 3, 19, 1024, 2048, "entropy", 0)
+    assert table.shape == (2975,) and np.isfinite(table).all()
+    for first, count in ((5, 3), (2974, 1), (1480, 8)):
+        got = net.score(syn.synth_frames_device(first, count, 1024, 2048, 3), "entropy").cpu().numpy()
+        assert np.array_equal(got, table[first:first + count]), (first, got, table[first:first + count])
+    srt = np.sort(table.astype(np.float32))
+    assert srt[128] - srt[127] > 0, "top-128 boundary of the bench pool must not be a tie"
 
 
 def test_rank_confidence_from_tfrecords(enet_c3k19, tmp_path):
@@ -576,6 +612,44 @@ def test_rank_confidence_from_tfrecords_pinned_uint8_prefetch(enet_c3k19, tmp_pa
         results.append(al.rank_confidence(net, batches(), num, np.arange(num), 3, prefetch=prefetch))
     (low_a, uc_a), (low_b, uc_b) = results
     assert set(low_a.tolist()) == set(low_b.tolist()) and (uc_a == uc_b).all()
+
+
+def test_pinned_ring_slot_reuse_with_rewrapped_batches(tmp_path):
+    """pin_buffers=2 with prefetch=2 forces every ring slot to be rewritten while earlier copies may still be
+    in flight; the batches reach prefetch_to_device sliced and re-wrapped (numpy round trip -> torch.from_numpy), i.e.
+    WITHOUT any Python attribute of the tensor InputStage yielded.  The copy-done events are keyed by the address of the
+    page-locked memory (tensortools.input.copy_issued), so every frame that arrives must equal its source."""
+    from test_input_cpu import write_pool
+    from semanticsegmentationactivelearning_amd.tensortools import InputStage, input as tin
+    num, h, w = 14, 96, 160
+    write_pool(str(tmp_path), num, h, w, with_label=False)
+    ref = InputStage(input_shape=[h, w], image_dtype=np.uint8)
+    ref.add_dataset("val", str(tmp_path), batch_size=3)
+    ref.init_iterator("val")
+    want = np.concatenate([np.asarray(b[0]) for b in ref])
+    stage = InputStage(input_shape=[h, w], image_dtype=np.uint8, pin_memory=True, pin_buffers=2)
+    stage.add_dataset("val", str(tmp_path), batch_size=3)
+    stage.init_iterator("val")
+    seen_slots = []
+
+    def batches():
+        pos = 0
+        for image, label, mask in stage:
+            assert image.is_pinned()
+            alias = torch.from_numpy(image.numpy()[:, :, :, :])  # new tensor object, same page-locked memory
+            ev = torch.cuda.Event()
+            ev.record()
+            assert tin.copy_issued(alias[1:], ev) is True  # a slice of the re-wrapped batch resolves to its slot
+            assert tin.copy_issued(np.zeros(4, dtype=np.uint8), ev) is False  # foreign memory: nothing to protect
+            seen_slots.append(alias.data_ptr())
+            yield alias, np.arange(pos, pos + len(alias))
+            pos += len(alias)
+    got = [x.clone() for x, _ in al.prefetch_to_device(batches(), depth=2)]
+    torch.cuda.synchronize()
+    got = torch.cat(got).cpu().numpy()
+    assert len(set(seen_slots)) == 2 and len(seen_slots) == 5  # 5 batches through 2 slots: each slot reused
+    assert np.array_equal(got, want)
+    assert all(len(v) == 0 or all(e.query() for e in v) for v in stage._pin_events.values())
 
 
 def test_rank_confidence_prefetch_and_uint8_host_batches(enet_c3k19):
@@ -800,13 +874,20 @@ def test_score_nonfinite_policy():
 
 def test_spatial_dropout_op():
     """xops.spatial_dropout (extra_ops.py:137-151): whole (image, channel) planes are either zero or scaled by
-    1/(1-rate); exact against the host twin of the seeded draw; deterministic; keep ratio ~ 1-rate"""
+    1/(1-rate); exact against oracle/dropout_oracle.py (plain-Python restatement of the seeded draw, no product code) and
+    against literal mask bits; deterministic; keep ratio ~ 1-rate"""
+    from oracle import dropout_oracle as dorc
+    # literal keep bits of (n=2, c=8, rate=0.5, seed=77): pins the draw independently of both implementations
+    lit = np.array([[0, 0, 1, 0, 1, 1, 1, 0], [1, 1, 0, 0, 1, 1, 0, 1]], dtype=np.float32)
+    assert np.array_equal(dorc.keep_mask(2, 8, 0.5, seed=77), lit)
+    ones = np.ones((2, 3, 5, 8), dtype=np.float32)
+    assert np.array_equal(xops.spatial_dropout(dev(ones), 0.5, seed=77).cpu().numpy(), 2.0 * ones * lit[:, None, None, :])
     rng = np.random.default_rng(2)
     for (n, h, w, c), rate in (((3, 6, 10, 64), 0.1), ((2, 5, 7, 19), 0.5), ((1, 4, 4, 128), 0.01)):
         x = (rng.normal(size=(n, h, w, c)) + 3.0).astype(np.float32)
         y = xops.spatial_dropout(dev(x), rate, seed=77).cpu().numpy()
-        keep = xops.spatial_dropout_keep_mask(n, c, rate, seed=77)
-        want = (x / np.float32(1.0 - rate)) * keep[:, None, None, :]
+        keep = dorc.keep_mask(n, c, rate, seed=77)
+        want = dorc.spatial_dropout(x, rate, seed=77)
         report_diff("spatial_dropout", y, want)
         per_plane = (y != 0).reshape(n, h * w, c)
         assert (per_plane.all(axis=1) | (~per_plane).any(axis=1) == True).all()
@@ -815,8 +896,9 @@ def test_spatial_dropout_op():
         assert np.array_equal(y, y2)
         y3 = xops.spatial_dropout(dev(x), rate, seed=78).cpu().numpy()
         assert rate < 0.05 or not np.array_equal(y, y3)
-    keep = xops.spatial_dropout_keep_mask(64, 128, 0.3, seed=5)
-    assert abs(keep.mean() - 0.7) < 0.02
+    x64 = np.ones((64, 1, 1, 128), dtype=np.float32)
+    kept = xops.spatial_dropout(dev(x64), 0.3, seed=5).cpu().numpy() != 0
+    assert abs(kept.mean() - 0.7) < 0.02 and np.array_equal(kept[:, 0, 0, :], dorc.keep_mask(64, 128, 0.3, seed=5) == 1)
     assert np.array_equal(xops.spatial_dropout(dev(x), 0.0).cpu().numpy(), x)
     with pytest.raises(ValueError):
         xops.spatial_dropout(dev(x), 1.0)

@@ -282,3 +282,60 @@ def test_glorot_matches_tf_fan_rule():
     assert w.dtype == np.float32 and np.abs(w).max() <= lim and np.abs(w).max() > 0.9 * lim
     a = init([32])  # conv_alpha uses the kernel initializer on a 1-D shape (enet_modules.py:442-449)
     assert np.abs(a).max() <= np.sqrt(6.0 / 64)
+
+
+def test_bench_score_digest_against_table(tmp_path, monkeypatch):
+    """bench.score_digest: SHA-256 of the float64 scores in frame order vs the same frames of the committed table; sentinel
+    (-1) entries and duplicates of a wrapped batch list are dropped; a differing bit is a mismatch; no table -> None"""
+    import bench
+    table = np.linspace(0.1, 0.9, 50)
+    key = bench.table_key("enet", 3, 19, 1024, 2048, "entropy", 0)
+    assert key == "enet_c3k19_1024x2048_entropy_seed0"
+    path = tmp_path / "pool_scores.npz"
+    np.savez(path, **{key: table})
+    monkeypatch.setattr(bench, "SCORE_TABLE", str(path))
+    idx = np.array([7, 3, -1, 12, 3, -1])
+    sc = np.where(idx >= 0, table[np.maximum(idx, 0)], np.inf)
+    d = bench.score_digest(idx, sc, key)
+    assert d["match"] is True and d["frames"] == 3 and d["sha256"] == d["expected_sha256"]
+    sc2 = sc.copy()
+    sc2[0] = np.nextafter(sc2[0], 1.0)
+    d2 = bench.score_digest(idx, sc2, key)
+    assert d2["match"] is False and 0 < d2["max_abs_diff"] < 1e-15
+    assert bench.score_digest(idx, sc, "no_such_key")["match"] is None
+    assert bench.score_digest(np.array([60]), np.array([0.5]), key)["match"] is None  # frame beyond the table
+
+
+def test_committed_pool_score_table_has_every_bench_config():
+    import bench
+    with np.load(bench.SCORE_TABLE) as z:
+        assert z[bench.table_key("enet", 3, 19, 1024, 2048, "entropy", 0)].shape == (bench.POOL,)
+        for key in (bench.table_key("icnet", 3, 19, 1024, 2048, "margin", 0), bench.table_key("enet", 4, 6, 1024, 2048, "entropy", 1)):
+            assert z[key].shape[0] >= 8 * (24 + 2) and z[key].dtype == np.float64 and np.isfinite(z[key]).all()
+
+
+def test_bench_watchdog_exits_nonzero_when_a_block_hangs():
+    """bench.Watchdog: a rendezvous / barrier that never returns ends the process with exit code 3 instead of hanging"""
+    import sys
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "with bench.Watchdog(0.5, 'test block'):\n    time.sleep(30)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=25)
+    assert r.returncode == 3 and b"TIMEOUT" in r.stderr
+    ok = ("import sys; sys.path.insert(0, %r); import bench\n"
+          "with bench.Watchdog(5, 'fast block'):\n    pass\nprint('done')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", ok], capture_output=True, timeout=25)
+    assert r.returncode == 0 and b"done" in r.stdout
+
+
+def test_bench_scaling_default_and_common_step_count():
+    """strong is the default with WORLD_SIZE > 1; every rank derives the same step count from ceil(POOL / world) (ADVICE
+    r02: per-rank ceil(len / batch) can differ between the long and the short shards, e.g. batch 7 on 8 ranks)"""
+    import bench
+    a = bench.parse([])
+    assert a.scaling is None and a.steps == 372 and a.dist_timeout > 0
+    for world, bs in ((8, 8), (8, 7), (2, 8), (3, 5)):
+        per = (bench.POOL + world - 1) // world
+        steps = (per + bs - 1) // bs
+        for rank in range(world):
+            mine = len(range(rank, bench.POOL, world))
+            assert mine <= per <= steps * bs

@@ -252,6 +252,9 @@ def test_full_resolution_frame_bit_exact(icnet19):
     want_mean, _, want_label = orc.score_logits(full, "margin")
     report_diff("label", e["label"].cpu().numpy(), want_label)
     report_diff("margin mean", s.cpu().numpy(), want_mean, exact=False, atol=1e-6)
+    from helpers import pool_score_table
+    table = pool_score_table("icnet", 3, 19, 1024, 2048, "margin", 0)
+    assert s.cpu().numpy()[0] == table[2], "HIP score of ICNet frame 2 != committed pool_scores.npz entry"
 
 
 def test_matches_golden_fixture(icnet19):

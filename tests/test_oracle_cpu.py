@@ -221,3 +221,16 @@ def test_rank_lowest_matches_reference_tail():
     ids, uc = orc.rank_lowest(scores, unl, 2)
     assert set(ids.tolist()) == {1, 5}
     assert uc.dtype == np.float32 and len(uc) == 5
+
+
+def test_dropout_oracle_literal_keep_bits_and_arithmetic():
+    """oracle/dropout_oracle.py (checker of xops.spatial_dropout, reference extra_ops.py:137-151): literal keep bits of the
+    seeded draw, tf.nn.dropout arithmetic (x / keep_prob) * keep, one draw per (image, channel) plane"""
+    from oracle import dropout_oracle as d
+    lit = np.array([[0, 0, 1, 0, 1, 1, 1, 0], [1, 1, 0, 0, 1, 1, 0, 1]], dtype=np.float32)
+    assert np.array_equal(d.keep_mask(2, 8, 0.5, seed=77), lit)
+    x = np.arange(2 * 2 * 3 * 8, dtype=np.float32).reshape(2, 2, 3, 8) + 1.0
+    y = d.spatial_dropout(x, 0.5, seed=77)
+    assert np.array_equal(y, (x / np.float32(0.5)) * lit[:, None, None, :])
+    assert abs(d.keep_mask(64, 128, 0.3, seed=5).mean() - 0.7) < 0.02
+    assert np.array_equal(d.keep_mask(3, 5, 0.0, seed=1), np.ones((3, 5), dtype=np.float32))

@@ -2,6 +2,9 @@
 [8,256,512,64] fp32 tensor = the stage-1 bottleneck's traffic), vs a linear copy."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# the probe kernels live in the measurement library only (python tools/phase_trace.py --build-measure)
+os.environ.setdefault("SSAL_LIB_PATH", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                      "semanticsegmentationactivelearning_amd", "libssal_hip_measure.so"))
 import torch
 from semanticsegmentationactivelearning_amd import _lib
 L = _lib.lib()

@@ -1,6 +1,9 @@
 """What the fp32 matrix pipe of this device sustains (bare MFMA loops), vs the 157.3 TFLOP/s spec."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# the probe kernels live in the measurement library only (python tools/phase_trace.py --build-measure)
+os.environ.setdefault("SSAL_LIB_PATH", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                      "semanticsegmentationactivelearning_amd", "libssal_hip_measure.so"))
 import torch
 from semanticsegmentationactivelearning_amd import _lib
 L = _lib.lib()

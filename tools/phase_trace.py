@@ -10,11 +10,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PKG = os.path.join(ROOT, "semanticsegmentationactivelearning_amd")
 TRACE_LIB = os.path.join(PKG, "libssal_hip_trace.so")
+# _lib reads SSAL_LIB_PATH when the package is first imported (build_trace_lib imports it too): set it up front
+os.environ["SSAL_LIB_PATH"] = TRACE_LIB
 
 
-def build_trace_lib():
+MEASURE_LIB = os.path.join(PKG, "libssal_hip_measure.so")
+
+
+def build_trace_lib(measure_only=False):
+    """-DSSAL_PHASE_TRACE: phase marks + ablation + env knobs (libssal_hip_trace.so); measure_only: -DSSAL_MEASURE alone
+    (libssal_hip_measure.so: ablation + env knobs, no s_memtime marks in the kernels -- the library A/B timings use)"""
     from semanticsegmentationactivelearning_amd import build as B
-    cmd = [shutil.which("hipcc") or "/opt/rocm/bin/hipcc"] + B.FLAGS + ["-DSSAL_PHASE_TRACE", "-o", TRACE_LIB] + B.sources()
+    out, flag = (MEASURE_LIB, "-DSSAL_MEASURE") if measure_only else (TRACE_LIB, "-DSSAL_PHASE_TRACE")
+    cmd = [shutil.which("hipcc") or "/opt/rocm/bin/hipcc"] + B.FLAGS + [flag, "-o", out] + B.sources(measure=True)
     print("[trace build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
 
@@ -37,11 +45,15 @@ MARKS_BY_LAYER = {"Bottleneck2_0": MARKS["Bottleneck4"],
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--build-only", action="store_true")
+    ap.add_argument("--build-measure", action="store_true", help="build libssal_hip_measure.so (-DSSAL_MEASURE) and exit")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("layers", nargs="*", default=["Bottleneck2_1", "Bottleneck1_1"])
     args = ap.parse_args()
+    if args.build_measure:
+        build_trace_lib(measure_only=True)
+        return
     src_dir = os.path.join(PKG, "csrc")
-    newest_src = max(os.path.getmtime(os.path.join(src_dir, f)) for f in os.listdir(src_dir))
+    newest_src = max(os.path.getmtime(os.path.join(src_dir, f)) for f in os.listdir(src_dir) if not f.startswith("."))
     stale = os.path.exists(TRACE_LIB) and os.path.getmtime(TRACE_LIB) < newest_src
     if args.build_only or stale or not os.path.exists(TRACE_LIB):
         build_trace_lib()

@@ -77,7 +77,13 @@ struct ConvDev {
     const float *w = nullptr;      // igemm layout (cin % 32 == 0) or raw HWIO (first convs)
     const float *scale = nullptr;  // [CoutP]
     const float *shift = nullptr;  // [CoutP]
+    const float *w_hwio = nullptr; // plain HWIO copy: only the layers of the blocks in fused_bneck() (else NULL)
 };
+
+// identity-shortcut bottlenecks with ENet's stage-2 shape (128 -> 32 -> 3x3 -> 128 on the 1/8-resolution map): the score
+// path runs them as ONE launch of ENet's fused bottleneck kernel (k_bottleneck_mfma, PReLU slopes = 0 == ReLU); the
+// three 1x1-layer launches of the per-layer path read / write 302 MB each at that size and are HBM-bound
+bool fused_bneck(const BneckSpec &b) { return !b.proj && b.cin == 128 && b.mid == 32 && b.cout == 128 && b.stride == 1; }
 
 // one materialised activation tensor: spatial divisor relative to the input and channel count
 struct ActSpec {
@@ -96,6 +102,7 @@ struct ssal_icnet {
     std::vector<ActSpec> acts;
     float *arena = nullptr;
     size_t arena_floats = 0;
+    const float *zeros128 = nullptr;  // PReLU slopes of the fused bottleneck launches (slope 0 == ReLU)
     bool committed = false;
 };
 
@@ -210,8 +217,10 @@ hipError_t run_conv(const ssal_icnet *net, const std::string &name, const float 
 }
 
 // runs everything up to the 1/4-resolution class logits (ICNET_SPEC conv6_cls)
+// fused: the score path (nobody reads the intermediate layer outputs) may run a whole block as one launch; the forward
+// path keeps one launch per ICNET_SPEC layer, so that every layer output of the last forward call is an endpoint
 hipError_t run_trunk(const ssal_icnet *net, const void *x, bool x_is_u8, int n, int h, int w, IcWorkspace &W,
-                     hipStream_t s)
+                     hipStream_t s, bool fused)
 {
     auto A = [&](const std::string &nm) { return W.act.at(nm); };
     // ---- medium-resolution branch / shared stem (section 1) ----
@@ -235,6 +244,19 @@ hipError_t run_trunk(const ssal_icnet *net, const void *x, bool x_is_u8, int n, 
             cw /= 2;
         }
         const int oh = ch / b.stride, ow = cw / b.stride;
+        if (fused && fused_bneck(b) && b.dil >= 1) {
+            // reduce -> 3x3 -> increase + identity shortcut -> ReLU == ENet's regular bottleneck with zero slopes: same
+            // (kh, kw, ci)-ascending fmaf chains, same folded batch-norm, same `fmaf(e, s, t) + x` merge; a ReLU written as
+            // PReLU(slope 0) yields -0.0 where max(v, 0) yields +0.0, which no later layer can tell apart (every consumer
+            // adds it into a +0-initialised chain)
+            const ConvDev &r = net->convs.at(nm + "_1x1_reduce"), &c3 = net->convs.at(nm + "_3x3"),
+                          &inc = net->convs.at(nm + "_1x1_increase");
+            HIP_RET(launch_bottleneck_mfma(cur, A(nm), n, ch, cw, b.cin, b.dil, r.w_hwio, r.scale, r.shift, net->zeros128,
+                                           c3.w_hwio, nullptr, c3.scale, c3.shift, net->zeros128, inc.w_hwio, inc.scale,
+                                           inc.shift, net->zeros128, s));
+            cur = A(nm);
+            continue;
+        }
         const float *shortcut = cur;
         if (b.proj) {
             HIP_RET(run_conv(net, nm + "_1x1_proj", cur, n, ch, cw, nullptr, false, false, A(nm + "_1x1_proj"), s));
@@ -280,7 +302,7 @@ int forward_any(ssal_icnet *net, const void *x_dev, bool u8, int n, int h, int w
     IcWorkspace W = carve(net, ws_dev, ws_bytes, n, h, w);
     if (!W.ok) return fail(SSAL_ENOMEM, "workspace too small: need %lld bytes, got %lld", (long long)W.bytes, (long long)ws_bytes);
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(run_trunk(net, x_dev, u8, n, h, w, W, s));
+    HIP_TRY(run_trunk(net, x_dev, u8, n, h, w, W, s, false));
     HIP_TRY(launch_resize_bilinear(W.act.at("conv6_cls"), n, h / 4, w / 4, net->classes, h, w, logits_dev, s));
     return SSAL_OK;
 }
@@ -298,7 +320,7 @@ int score_any(ssal_icnet *net, const void *x_dev, bool u8, int n, int h, int w, 
     IcWorkspace W = carve(net, ws_dev, ws_bytes, n, h, w);
     if (!W.ok) return fail(SSAL_ENOMEM, "workspace too small: need %lld bytes, got %lld", (long long)W.bytes, (long long)ws_bytes);
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(run_trunk(net, x_dev, u8, n, h, w, W, s));
+    HIP_TRY(run_trunk(net, x_dev, u8, n, h, w, W, s, true));
     HIP_TRY(launch_upscore(W.act.at("conv6_cls"), n, h / 4, w / 4, net->classes, measure, threshold, W.partial,
                            label_dev, mask_dev, conf_dev, s));
     HIP_TRY(launch_reduce_mean(W.partial, n, upscore_blocks(h / 4, w / 4), (double)h * (double)w, scores_dev, s));
@@ -380,11 +402,18 @@ SSAL_API int ssal_icnet_commit(ssal_icnet *net, void *stream)
     for (const auto &t : net->tensors)
         if (!t.set) return fail(SSAL_ESTATE, "tensor '%s' has not been set", t.name.c_str());
     ArenaBuilder ab;
-    struct Off { size_t w, s, t; };
+    struct Off { size_t w, s, t, hwio; };
     std::map<std::string, Off> offs;
     std::vector<float> s, t, wt;
+    std::map<std::string, bool> wants_hwio;
+    for (int i = 0; i < kNumBnecks; ++i)
+        if (fused_bneck(kBnecks[i]))
+            for (const char *suf : {"_1x1_reduce", "_3x3", "_1x1_increase"}) wants_hwio[std::string(kBnecks[i].name) + suf] = true;
+    const size_t zeros_off = ab.push(std::vector<float>(128, 0.0f));
     for (const ConvSpec &sp : net->specs) {
         Off o;
+        o.hwio = (size_t)-1;
+        if (wants_hwio.count(sp.name)) o.hwio = ab.push(T(net, sp.name + ".kernel"));
         const std::vector<float> &k = T(net, sp.name + ".kernel");
         if (sp.cin % 32 == 0) {
             wt.resize(igemm_relayout_floats(sp.k, sp.k, sp.cin, sp.cout));
@@ -421,8 +450,10 @@ SSAL_API int ssal_icnet_commit(ssal_icnet *net, void *stream)
         d.w = net->arena + o.w;
         d.scale = net->arena + o.s;
         d.shift = net->arena + o.t;
+        d.w_hwio = o.hwio == (size_t)-1 ? nullptr : net->arena + o.hwio;
         net->convs[sp.name] = d;
     }
+    net->zeros128 = net->arena + zeros_off;
     net->committed = true;
     return SSAL_OK;
 }

@@ -21,7 +21,7 @@ step pytest_gpu 900 python -m pytest tests -m gpu -q -p no:cacheprovider ${PYTES
 step bench 600 python bench.py --steps $STEPS --warmup 2
 if [ "${SKIP_PROF:-0}" != "1" ]; then
     export TMPDIR=/tmp
-    step rocprof 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-roofline
+    step rocprof 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-secondary --no-roofline
     find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -r -I{} sh -c 'echo "--- {}"; head -n 25 {}' | tee -a $OUT/summary.log
 fi
 echo "=== done ===" | tee -a $OUT/summary.log

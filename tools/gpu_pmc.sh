@@ -6,7 +6,7 @@ MODEL=${1:-enet}
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python3 bench.py --model $MODEL --steps 2 --warmup 1 --no-cpu-baseline --no-roofline"
+CMD="python3 bench.py --model $MODEL --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-roofline"
 run() { # name counters...
     local name=$1; shift
     echo "=== pmc $MODEL $name: $*" | tee -a $OUT/pmc_summary.log

@@ -1,7 +1,7 @@
 #!/bin/bash
 set -u
 OUT=gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
-CMD="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline"
+CMD="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-roofline"
 run() { local name=$1; shift
     timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/pmc2_$name -- $CMD > $OUT/pmc2_$name.log 2>&1
     local rc=$?; echo "pmc2 $name rc=$rc"; if [ $rc -ge 124 ]; then exit $rc; fi; }

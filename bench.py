@@ -125,6 +125,9 @@ def parse(argv=None):
     ap.add_argument("--allow-nondefault-knobs", action="store_true",
                     help="measurement runs only (tools/*.sh with a -DSSAL_MEASURE library): time the library although "
                          "ssal_debug_get_knobs() says a switch is off its default; the JSON line still reports them")
+    ap.add_argument("--knob", action="append", default=[], metavar="NAME=VALUE",
+                    help="measurement runs only: ssal_debug_set_knob(NAME, VALUE) before anything is timed (needs "
+                         "--allow-nondefault-knobs; the JSON line reports the knobs)")
     ap.add_argument("--allow-digest-mismatch", action="store_true",
                     help="measurement builds whose results are invalid by construction (ablation): report, do not fail")
     return ap.parse_args(argv)
@@ -461,6 +464,9 @@ def main(argv=None):
     world, rank, use_dist = ctx["world"], ctx["rank"], ctx["use_dist"]
     scaling = args.scaling or ("strong" if world > 1 else "weak")
 
+    for kv in args.knob:
+        name, value = kv.split("=", 1)
+        _lib.set_knob(name, int(value))
     knobs = _lib.get_knobs()
     if not knobs["defaults"] and not args.allow_nondefault_knobs:
         raise SystemExit("refusing to time a library whose switches are not at their shipping values: %s" % knobs)

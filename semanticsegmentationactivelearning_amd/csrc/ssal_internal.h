@@ -106,6 +106,7 @@ hipError_t launch_upsample_mfma(const float *x, float *y, const uint8_t *code, i
 struct Knobs {
     int bnk_tw;      // 16 = force 8x16 tiles in the 128-channel bottleneck kernels
     int bnk_xcd;     // 1 = XCD-aware tile order in the 128-channel bottleneck kernels
+    int img_groups;  // stage 2 + 3 of ENet: the batch runs as this many image groups on side streams (default 2; 1 = everything on the caller's stream)
 #ifdef SSAL_MEASURE
     int ablate;      // measurement builds only: 1 = stop after the projection phase, 2 = skip it (results invalid)
 #endif

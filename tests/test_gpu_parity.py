@@ -904,6 +904,32 @@ def test_spatial_dropout_op():
         xops.spatial_dropout(dev(x), 1.0)
 
 
+def test_image_group_streams_are_bit_identical(enet_c3k19):
+    """stages 2 + 3 run as `img_groups` image chains on library-owned side streams (default 2): logits, labels and scores
+    must not depend on the grouping (1 = caller's stream only, 2, 4; a batch the group count does not divide falls back
+    to one stream), and back-to-back calls on the same workspace must not race (the join precedes stage 4)"""
+    net, _ = enet_c3k19
+    x = syn.synth_frames_device(40, 4, 128, 256, 3)
+    x3 = syn.synth_frames_device(40, 3, 128, 256, 3)
+    ref = None
+    try:
+        for g in (1, 2, 4):
+            _lib.set_knob("img_groups", g)
+            outs = []
+            for _ in range(3):
+                s, e = net.score(x, "entropy", return_label=True)
+                outs.append((s.cpu().numpy(), e["label"].cpu().numpy(), net(x, training=False).cpu().numpy(),
+                             net.score(x3, "entropy").cpu().numpy()))
+            for o in outs[1:]:
+                assert all(np.array_equal(a, b) for a, b in zip(o, outs[0]))
+            if ref is None:
+                ref = outs[0]
+            assert all(np.array_equal(a, b) for a, b in zip(outs[0], ref)), "img_groups=%d changes the result" % g
+    finally:
+        _lib.set_knob("img_groups", 2)
+    assert _lib.get_knobs()["defaults"] == 1
+
+
 def test_repeated_calls_do_not_grow_device_memory(enet_c3k19):
     """ENet.__call__ keeps only the most recent logits / endpoints (an eager stand-in for the reference's
     once-per-graph-build `outputs.append`, enet.py:405): memory stays flat over many calls"""

@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -113,8 +114,8 @@ struct ssal_enet {
     float *arena = nullptr;
     size_t arena_floats = 0;
     bool committed = false;
-    // side streams + events of the image-group schedule of stages 2 + 3 (created on first use, run_trunk)
-    hipStream_t side[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // events of the image-group schedule (created on first use, run_net); the side streams are process-wide
+    hipStream_t side[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // borrowed, not owned
     hipEvent_t fork_ev = nullptr, join_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
@@ -223,10 +224,8 @@ SSAL_API int ssal_enet_destroy(ssal_enet *net)
 {
     if (!net) return SSAL_OK;
     if (net->arena) (void)hipFree(net->arena);
-    for (int g = 0; g < 8; ++g) {
-        if (net->side[g]) (void)hipStreamDestroy(net->side[g]);
+    for (int g = 0; g < 8; ++g)
         if (net->join_ev[g]) (void)hipEventDestroy(net->join_ev[g]);
-    }
     if (net->fork_ev) (void)hipEventDestroy(net->fork_ev);
     delete net;
     return SSAL_OK;
@@ -641,66 +640,104 @@ int check_dims(const ssal_enet *net, int n, int h, int w)
     return SSAL_OK;
 }
 
-// runs Initial .. Bottleneck5_1; returns the 16-channel half-resolution tensor feeding Final
-hipError_t run_trunk(ssal_enet *net, const void *x, bool x_is_u8, int n, int h, int w, NetWorkspace &W,
-                     const float **trunk_out, hipStream_t s)
+// layer li (0 = Initial .. 27 = Bottleneck5_1) on the fixed buffer plan of the workspace: Initial -> a0; 1_0: a0 -> s1a;
+// 1_1..1_4 ping-pong s1a / s1b; 2_0: s1a -> s2a; 2_1..3_8 ping-pong s2a / s2b (ends in s2a); 4_0: s2a -> s1a; 4_1, 4_2
+// ping-pong; 5_0: s1a -> a0; 5_1: a0 -> a1.  V holds the buffers of the images this call works on.
+hipError_t run_layer_idx(const ssal_enet *net, int li, const void *x, bool x_is_u8, const NetWorkspace &V, int n, int h,
+                         int w, hipStream_t s)
 {
-    const std::vector<DevLayer> &L = net->layers;
-    HIP_RET(launch_initial(x, x_is_u8, n, h, w, net->c_in, L[0].w, L[0].scale, L[0].shift, L[0].alpha, W.a0, s));
-    int li = 1;
-    // stage 1
-    HIP_RET(run_down(L[li++], W.a0, n, h / 2, w / 2, W.s1a, W.code1, W.T, s));
-    float *cur = W.s1a, *oth = W.s1b;
-    for (int k = 0; k < 4; ++k) {
-        HIP_RET(run_regular(L[li++], cur, n, h / 4, w / 4, oth, W.T, s));
-        float *t = cur; cur = oth; oth = t;
-    }
-    // stage 2 + 3
-    HIP_RET(run_down(L[li++], cur, n, h / 4, w / 4, W.s2a, W.code2, W.T, s));
-    float *c2 = W.s2a, *o2 = W.s2b;
-    const int G = ssal::knobs().img_groups;
-    if (G > 1 && G <= 8 && n % G == 0 && g_use_mfma && !ssal::prof_enabled()) {
-        // image-group schedule: images are independent, so the 16 bottlenecks of stages 2 + 3 run as G chains of n / G
-        // images on G side streams (fork / join with events; the caller's stream order is kept).  A launch of 1024 tiles
-        // fills the 768 workgroup slots 1.33 times; two chains of 512-tile launches keep the chip filled across the
-        // launch boundaries of each other.  Measured (same box, 60 steps): G = 2 +1.5 ... 2 %, G = 4 -6 %, G = 8 -20 %
-        // (launches too small); an extra one-launch offset between the chains changes nothing.  Identical bits.
+    const DevLayer &L = net->layers[li];
+    if (li == 0) return launch_initial(x, x_is_u8, n, h, w, net->c_in, L.w, L.scale, L.shift, L.alpha, V.a0, s);
+    if (li == 1) return run_down(L, V.a0, n, h / 2, w / 2, V.s1a, V.code1, V.T, s);
+    if (li <= 5) return run_regular(L, (li - 2) % 2 == 0 ? V.s1a : V.s1b, n, h / 4, w / 4, (li - 2) % 2 == 0 ? V.s1b : V.s1a, V.T, s);
+    if (li == 6) return run_down(L, V.s1a, n, h / 4, w / 4, V.s2a, V.code2, V.T, s);
+    if (li <= 22) return run_regular(L, (li - 7) % 2 == 0 ? V.s2a : V.s2b, n, h / 8, w / 8, (li - 7) % 2 == 0 ? V.s2b : V.s2a, V.T, s);
+    if (li == 23) return run_up(L, V.s2a, n, h / 8, w / 8, V.s1a, V.code2, nullptr, V.T, s);
+    if (li <= 25) return run_regular(L, li == 24 ? V.s1a : V.s1b, n, h / 4, w / 4, li == 24 ? V.s1b : V.s1a, V.T, s);
+    if (li == 26) return run_up(L, V.s1a, n, h / 4, w / 4, V.a0, V.code1, nullptr, V.T, s);
+    return run_regular(L, V.a0, n, h / 2, w / 2, V.a1, V.T, s);
+}
+
+// Final (transposed conv) fused with the score (k_final_score): outputs of the images [i0, i0 + n)
+struct FinalOut {
+    float *logits;
+    int measure;
+    float threshold;
+    uint8_t *label, *mask;
+    float *conf;
+};
+
+hipError_t run_final(const ssal_enet *net, const NetWorkspace &V, const FinalOut &f, long i0, int n, int h, int w,
+                     hipStream_t s)
+{
+    const long px = (long)h * w;
+    return launch_final_score(V.a1, n, h / 2, w / 2, net->layers[kNumLayers - 1].w, net->classes,
+                              f.logits ? f.logits + i0 * px * net->classes : nullptr, f.measure, f.threshold, V.partial,
+                              f.label ? f.label + i0 * px : nullptr, f.mask ? f.mask + i0 * px : nullptr,
+                              f.conf ? f.conf + i0 * px : nullptr, s);
+}
+
+// runs Initial .. Bottleneck5_1 and Final + score (per-block float64 partials in W.partial)
+hipError_t run_net(ssal_enet *net, const void *x, bool x_is_u8, int n, int h, int w, NetWorkspace &W,
+                   const FinalOut &fin, hipStream_t s)
+{
+    // image-group schedule: images are independent, so a span of layers runs as G chains of ~n / G images on G
+    // library-owned side streams (fork / join with events; the caller's stream order is kept).  Launches of different
+    // chains overlap on the chip: the tail of one launch (the last, partly filled round of workgroups) and the load-only
+    // head of the next are covered by the other chain's workgroups.  Measured on one box, batch 8, 40-60 steps, identical
+    // bits in every row (profiles/r03_ab_image_group_streams.txt): one stream 2062 images/s; stages 2 + 3 in two chains
+    // 2087-2125; Bottleneck1_0..5_1 2126-2149; Initial..5_1 2154-2160; Initial..Final + score 2167-2174 (+5.2 %, the
+    // default); four chains 1897-1915 (launches too small); an extra one-launch offset between two chains: no change.
+    const ssal::Knobs &kn = ssal::knobs();
+    int G = kn.img_groups, ga = 7, gb = 23;  // span 0: Bottleneck2_1 .. Bottleneck3_8
+    if (kn.img_span == 1) ga = 6;
+    else if (kn.img_span == 2) { ga = 1; gb = 28; }
+    else if (kn.img_span == 3) { ga = 0; gb = 28; }
+    else if (kn.img_span == 4) { ga = 0; gb = 29; }  // layer 28 = Final + score
+    if (G < 2 || G > 8 || n < G || !g_use_mfma || ssal::prof_enabled()) G = 1;
+    NetWorkspace V[8];
+    int first[9];  // group g = images [first[g], first[g + 1]): as even as n allows (a pool's last batch may be odd)
+    for (int g = 0; g <= G; ++g) first[g] = (int)((long)g * n / G);
+    const size_t xelt = x_is_u8 ? 1 : 4;
+    if (G > 1) {
         if (!net->fork_ev) HIP_RET(hipEventCreateWithFlags(&net->fork_ev, hipEventDisableTiming));
         for (int g = 0; g < G; ++g) {
-            if (!net->side[g]) HIP_RET(hipStreamCreateWithFlags(&net->side[g], hipStreamNonBlocking));
+            if (!net->side[g]) HIP_RET(ssal::side_stream(g, &net->side[g]));
             if (!net->join_ev[g]) HIP_RET(hipEventCreateWithFlags(&net->join_ev[g], hipEventDisableTiming));
-        }
-        HIP_RET(hipEventRecord(net->fork_ev, s));
-        const int ng = n / G;
-        const long goff = (long)ng * (h / 8) * (w / 8) * 128;
-        for (int g = 0; g < G; ++g) HIP_RET(hipStreamWaitEvent(net->side[g], net->fork_ev, 0));
-        for (int k = 0; k < 16; ++k) {  // layer-major issue order
-            for (int g = 0; g < G; ++g)
-                HIP_RET(run_regular(L[li], c2 + g * goff, ng, h / 8, w / 8, o2 + g * goff, W.T, net->side[g]));
-            ++li;
-            float *t = c2; c2 = o2; o2 = t;
-        }
-        for (int g = 0; g < G; ++g) {
-            HIP_RET(hipEventRecord(net->join_ev[g], net->side[g]));
-            HIP_RET(hipStreamWaitEvent(s, net->join_ev[g], 0));
-        }
-    } else {
-        for (int k = 0; k < 16; ++k) {
-            HIP_RET(run_regular(L[li++], c2, n, h / 8, w / 8, o2, W.T, s));
-            float *t = c2; c2 = o2; o2 = t;
+            const long i0 = first[g];
+            V[g] = W;
+            V[g].a0 += i0 * (h / 2) * (w / 2) * 16;  V[g].a1 += i0 * (h / 2) * (w / 2) * 16;
+            V[g].s1a += i0 * (h / 4) * (w / 4) * 64; V[g].s1b += i0 * (h / 4) * (w / 4) * 64;
+            V[g].s2a += i0 * (h / 8) * (w / 8) * 128; V[g].s2b += i0 * (h / 8) * (w / 8) * 128;
+            V[g].code1 += i0 * (h / 4) * (w / 4) * 16; V[g].code2 += i0 * (h / 8) * (w / 8) * 64;
+            V[g].partial += i0 * final_score_blocks(h / 2, w / 2);
         }
     }
-    // stage 4 (stage-1 buffers are free again)
-    HIP_RET(run_up(L[li++], c2, n, h / 8, w / 8, W.s1a, W.code2, nullptr, W.T, s));
-    cur = W.s1a; oth = W.s1b;
-    for (int k = 0; k < 2; ++k) {
-        HIP_RET(run_regular(L[li++], cur, n, h / 4, w / 4, oth, W.T, s));
-        float *t = cur; cur = oth; oth = t;
+    for (int li = 0; li < 29; ++li) {
+        if (G > 1 && li >= ga && li < gb) {
+            if (li == ga) {
+                HIP_RET(hipEventRecord(net->fork_ev, s));
+                for (int g = 0; g < G; ++g) HIP_RET(hipStreamWaitEvent(net->side[g], net->fork_ev, 0));
+            }
+            for (int g = 0; g < G; ++g) {  // layer-major issue order
+                const int ng = first[g + 1] - first[g];
+                if (li == 28)
+                    HIP_RET(run_final(net, V[g], fin, first[g], ng, h, w, net->side[g]));
+                else
+                    HIP_RET(run_layer_idx(net, li, (const char *)x + (size_t)first[g] * h * w * net->c_in * xelt, x_is_u8,
+                                          V[g], ng, h, w, net->side[g]));
+            }
+            if (li == gb - 1)
+                for (int g = 0; g < G; ++g) {
+                    HIP_RET(hipEventRecord(net->join_ev[g], net->side[g]));
+                    HIP_RET(hipStreamWaitEvent(s, net->join_ev[g], 0));
+                }
+        } else if (li == 28) {
+            HIP_RET(run_final(net, W, fin, 0, n, h, w, s));
+        } else {
+            HIP_RET(run_layer_idx(net, li, x, x_is_u8, W, n, h, w, s));
+        }
     }
-    // stage 5
-    HIP_RET(run_up(L[li++], cur, n, h / 4, w / 4, W.a0, W.code1, nullptr, W.T, s));
-    HIP_RET(run_regular(L[li++], W.a0, n, h / 2, w / 2, W.a1, W.T, s));
-    *trunk_out = W.a1;
     return hipSuccess;
 }
 }  // namespace
@@ -722,12 +759,9 @@ static int forward_any(ssal_enet *net, const void *x_dev, bool x_is_u8, int n, i
     if (!W.ok) return fail(SSAL_ENOMEM, "workspace too small: need %lld bytes, got %lld",
                            (long long)W.bytes, (long long)ws_bytes);
     hipStream_t s = (hipStream_t)stream;
-    const float *trunk = nullptr;
-    HIP_TRY(run_trunk(net, x_dev, x_is_u8, n, h, w, W, &trunk, s));
     // logits only: the score outputs of the fused kernel go to the scratch partial buffer
-    HIP_TRY(launch_final_score(trunk, n, h / 2, w / 2, net->layers[kNumLayers - 1].w, net->classes,
-                               logits_dev, SSAL_MEASURE_CONFIDENCE, 0.0f, W.partial, nullptr,
-                               nullptr, nullptr, s));
+    const FinalOut fin = {logits_dev, SSAL_MEASURE_CONFIDENCE, 0.0f, nullptr, nullptr, nullptr};
+    HIP_TRY(run_net(net, x_dev, x_is_u8, n, h, w, W, fin, s));
     return SSAL_OK;
 }
 
@@ -756,11 +790,8 @@ static int score_any(ssal_enet *net, const void *x_dev, bool x_is_u8, int n, int
     if (!W.ok) return fail(SSAL_ENOMEM, "workspace too small: need %lld bytes, got %lld",
                            (long long)W.bytes, (long long)ws_bytes);
     hipStream_t s = (hipStream_t)stream;
-    const float *trunk = nullptr;
-    HIP_TRY(run_trunk(net, x_dev, x_is_u8, n, h, w, W, &trunk, s));
-    HIP_TRY(launch_final_score(trunk, n, h / 2, w / 2, net->layers[kNumLayers - 1].w, net->classes,
-                               nullptr, measure, threshold, W.partial, label_dev, mask_dev,
-                               conf_dev, s));
+    const FinalOut fin = {nullptr, measure, threshold, label_dev, mask_dev, conf_dev};
+    HIP_TRY(run_net(net, x_dev, x_is_u8, n, h, w, W, fin, s));
     HIP_TRY(launch_reduce_mean(W.partial, n, final_score_blocks(h / 2, w / 2), (double)h * (double)w,
                                scores_dev, s));
     return SSAL_OK;
@@ -1134,6 +1165,22 @@ void prof_end(hipStream_t s)
 }
 }  // namespace ssal
 
+namespace ssal {
+hipError_t side_stream(int g, hipStream_t *out)
+{
+    static hipStream_t pool[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    static std::mutex mu;
+    if (g < 0 || g >= 8) return hipErrorInvalidValue;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!pool[g]) {
+        hipError_t e = hipStreamCreateWithFlags(&pool[g], hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+    }
+    *out = pool[g];
+    return hipSuccess;
+}
+}  // namespace ssal
+
 SSAL_API int ssal_set_kernel_family(int use_mfma)
 {
     g_use_mfma = use_mfma != 0;
@@ -1165,6 +1212,7 @@ SSAL_API int ssal_debug_set_knob(const char *name, int value)
     if (n == "bnk_tw") k.bnk_tw = value;
     else if (n == "bnk_xcd") k.bnk_xcd = value;
     else if (n == "img_groups") k.img_groups = value;
+    else if (n == "img_span") k.img_span = value;
 #ifdef SSAL_MEASURE
     else if (n == "ablate") k.ablate = value;
 #endif
@@ -1176,18 +1224,18 @@ SSAL_API int ssal_debug_set_knob(const char *name, int value)
 // refuses to time a library whose knobs are not at their defaults
 SSAL_API int ssal_debug_get_knobs(char *json_out, int64_t cap)
 {
-    if (!json_out || cap < 160) return fail(SSAL_EINVAL, "json_out too small");
+    if (!json_out || cap < 200) return fail(SSAL_EINVAL, "json_out too small");
     const ssal::Knobs &k = ssal::knobs();
     int measure = 0, ablate = 0;
 #ifdef SSAL_MEASURE
     measure = 1;
     ablate = k.ablate;
 #endif
-    const int dflt = g_use_mfma && k.bnk_tw == 0 && k.bnk_xcd == 1 && k.img_groups == 2 && ablate == 0 && !ssal::prof_enabled()
+    const int dflt = g_use_mfma && k.bnk_tw == 0 && k.bnk_xcd == 1 && k.img_groups == 2 && k.img_span == 4 && ablate == 0 && !ssal::prof_enabled()
                      && ssal::g_trace_buf == nullptr;
-    snprintf(json_out, (size_t)cap, "{\"kernel_family\": %d, \"bnk_tw\": %d, \"bnk_xcd\": %d, \"img_groups\": %d, "
+    snprintf(json_out, (size_t)cap, "{\"kernel_family\": %d, \"bnk_tw\": %d, \"bnk_xcd\": %d, \"img_groups\": %d, \"img_span\": %d, "
              "\"ablate\": %d, \"measure_build\": %d, \"profiling\": %d, \"defaults\": %d}", g_use_mfma ? 1 : 0,
-             k.bnk_tw, k.bnk_xcd, k.img_groups, ablate, measure, ssal::prof_enabled() ? 1 : 0, dflt);
+             k.bnk_tw, k.bnk_xcd, k.img_groups, k.img_span, ablate, measure, ssal::prof_enabled() ? 1 : 0, dflt);
     return SSAL_OK;
 }
 

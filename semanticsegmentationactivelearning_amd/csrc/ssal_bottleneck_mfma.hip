@@ -1008,6 +1008,7 @@ Knobs &knobs()
         q.bnk_tw = 0;
         q.bnk_xcd = 1;
         q.img_groups = 2;
+        q.img_span = 4;
 #ifdef SSAL_MEASURE  // measurement builds only: the product library reads no environment
         auto env = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
         q.bnk_tw = env("SSAL_BNK_TW", 0);

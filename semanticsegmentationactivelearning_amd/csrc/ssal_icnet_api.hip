@@ -104,6 +104,9 @@ struct ssal_icnet {
     size_t arena_floats = 0;
     const float *zeros128 = nullptr;  // PReLU slopes of the fused bottleneck launches (slope 0 == ReLU)
     bool committed = false;
+    // events of the image-group schedule of the score path (created on first use); the side streams are process-wide
+    hipStream_t side[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork_ev = nullptr, join_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace {
@@ -217,29 +220,43 @@ hipError_t run_conv(const ssal_icnet *net, const std::string &name, const float 
 }
 
 // runs everything up to the 1/4-resolution class logits (ICNET_SPEC conv6_cls)
+// one chain of the image-group schedule: a contiguous range of the batch with its views of the workspace and its stream
+struct Grp {
+    IcWorkspace W;
+    const void *x;
+    int n;
+    hipStream_t s;
+    float *A(const std::string &nm) const { return W.act.at(nm); }
+};
+
 // fused: the score path (nobody reads the intermediate layer outputs) may run a whole block as one launch; the forward
-// path keeps one launch per ICNET_SPEC layer, so that every layer output of the last forward call is an endpoint
-hipError_t run_trunk(const ssal_icnet *net, const void *x, bool x_is_u8, int n, int h, int w, IcWorkspace &W,
-                     hipStream_t s, bool fused)
+// path keeps one launch per ICNET_SPEC layer, so that every layer output of the last forward call is an endpoint.
+// Every layer is issued for all groups before the next layer (layer-major order: the chains advance together on their
+// streams instead of one chain's 70 launches queueing up in front of the other's).
+hipError_t run_trunk(const ssal_icnet *net, std::vector<Grp> &grp, bool x_is_u8, int h, int w, bool fused)
 {
-    auto A = [&](const std::string &nm) { return W.act.at(nm); };
+#define EACH(expr)                                     \
+    for (Grp & q : grp) {                              \
+        hipError_t e_ = (expr);                        \
+        if (e_ != hipSuccess) return e_;               \
+    }
     // ---- medium-resolution branch / shared stem (section 1) ----
     {
         const ConvDev &c = net->convs.at("conv1_1_3x3_s2");
-        HIP_RET(launch_conv_first(x, x_is_u8, n, h, w, net->c_in, 2, c.w, c.scale, c.shift, A("conv1_1_3x3_s2"), s));
+        EACH(launch_conv_first(q.x, x_is_u8, q.n, h, w, net->c_in, 2, c.w, c.scale, c.shift, q.A("conv1_1_3x3_s2"), q.s));
     }
-    HIP_RET(run_conv(net, "conv1_2_3x3", A("conv1_1_3x3_s2"), n, h / 4, w / 4, nullptr, true, false, A("conv1_2_3x3"), s));
-    HIP_RET(run_conv(net, "conv1_3_3x3", A("conv1_2_3x3"), n, h / 4, w / 4, nullptr, true, false, A("conv1_3_3x3"), s));
-    HIP_RET(launch_maxpool3x3_s2(A("conv1_3_3x3"), n, h / 4, w / 4, 64, A("pool1_3x3_s2"), s));
-    const float *cur = A("pool1_3x3_s2");
+    EACH(run_conv(net, "conv1_2_3x3", q.A("conv1_1_3x3_s2"), q.n, h / 4, w / 4, nullptr, true, false, q.A("conv1_2_3x3"), q.s));
+    EACH(run_conv(net, "conv1_3_3x3", q.A("conv1_2_3x3"), q.n, h / 4, w / 4, nullptr, true, false, q.A("conv1_3_3x3"), q.s));
+    EACH(launch_maxpool3x3_s2(q.A("conv1_3_3x3"), q.n, h / 4, w / 4, 64, q.A("pool1_3x3_s2"), q.s));
+    std::string cur = "pool1_3x3_s2";
     int ch = h / 8, cw = w / 8;
     for (int i = 0; i < kNumBnecks; ++i) {
         const BneckSpec &b = kBnecks[i];
         const std::string nm = b.name;
         if (i == kStemBnecks) {
             // section 2: conv3_1_sub4 = resize_bilinear(conv3_1, 1/2)
-            HIP_RET(launch_resize_bilinear(cur, n, ch, cw, 256, ch / 2, cw / 2, A("conv3_1_sub4"), s));
-            cur = A("conv3_1_sub4");
+            EACH(launch_resize_bilinear(q.A(cur), q.n, ch, cw, 256, ch / 2, cw / 2, q.A("conv3_1_sub4"), q.s));
+            cur = "conv3_1_sub4";
             ch /= 2;
             cw /= 2;
         }
@@ -251,45 +268,46 @@ hipError_t run_trunk(const ssal_icnet *net, const void *x, bool x_is_u8, int n, 
             // adds it into a +0-initialised chain)
             const ConvDev &r = net->convs.at(nm + "_1x1_reduce"), &c3 = net->convs.at(nm + "_3x3"),
                           &inc = net->convs.at(nm + "_1x1_increase");
-            HIP_RET(launch_bottleneck_mfma(cur, A(nm), n, ch, cw, b.cin, b.dil, r.w_hwio, r.scale, r.shift, net->zeros128,
-                                           c3.w_hwio, nullptr, c3.scale, c3.shift, net->zeros128, inc.w_hwio, inc.scale,
-                                           inc.shift, net->zeros128, s));
-            cur = A(nm);
+            EACH(launch_bottleneck_mfma(q.A(cur), q.A(nm), q.n, ch, cw, b.cin, b.dil, r.w_hwio, r.scale, r.shift,
+                                        net->zeros128, c3.w_hwio, nullptr, c3.scale, c3.shift, net->zeros128, inc.w_hwio,
+                                        inc.scale, inc.shift, net->zeros128, q.s));
+            cur = nm;
             continue;
         }
-        const float *shortcut = cur;
+        std::string shortcut = cur;
         if (b.proj) {
-            HIP_RET(run_conv(net, nm + "_1x1_proj", cur, n, ch, cw, nullptr, false, false, A(nm + "_1x1_proj"), s));
-            shortcut = A(nm + "_1x1_proj");
+            EACH(run_conv(net, nm + "_1x1_proj", q.A(cur), q.n, ch, cw, nullptr, false, false, q.A(nm + "_1x1_proj"), q.s));
+            shortcut = nm + "_1x1_proj";
         }
-        HIP_RET(run_conv(net, nm + "_1x1_reduce", cur, n, ch, cw, nullptr, true, false, A(nm + "_1x1_reduce"), s));
-        HIP_RET(run_conv(net, nm + "_3x3", A(nm + "_1x1_reduce"), n, oh, ow, nullptr, true, false, A(nm + "_3x3"), s));
-        HIP_RET(run_conv(net, nm + "_1x1_increase", A(nm + "_3x3"), n, oh, ow, shortcut, true, false, A(nm), s));
-        cur = A(nm);
+        EACH(run_conv(net, nm + "_1x1_reduce", q.A(cur), q.n, ch, cw, nullptr, true, false, q.A(nm + "_1x1_reduce"), q.s));
+        EACH(run_conv(net, nm + "_3x3", q.A(nm + "_1x1_reduce"), q.n, oh, ow, nullptr, true, false, q.A(nm + "_3x3"), q.s));
+        EACH(run_conv(net, nm + "_1x1_increase", q.A(nm + "_3x3"), q.n, oh, ow, q.A(shortcut), true, false, q.A(nm), q.s));
+        cur = nm;
         ch = oh;
         cw = ow;
     }
     // pyramid pooling + conv5_4_k1
-    HIP_RET(launch_ppm(cur, n, ch, cw, 1024, W.pooled, A("conv5_3_sum"), s));
-    HIP_RET(run_conv(net, "conv5_4_k1", A("conv5_3_sum"), n, ch, cw, nullptr, true, false, A("conv5_4_k1"), s));
+    EACH(launch_ppm(q.A(cur), q.n, ch, cw, 1024, q.W.pooled, q.A("conv5_3_sum"), q.s));
+    EACH(run_conv(net, "conv5_4_k1", q.A("conv5_3_sum"), q.n, ch, cw, nullptr, true, false, q.A("conv5_4_k1"), q.s));
     // ---- high-resolution branch (section 3) ----
     {
         const ConvDev &c = net->convs.at("conv1_sub1");
-        HIP_RET(launch_conv_first(x, x_is_u8, n, h, w, net->c_in, 1, c.w, c.scale, c.shift, A("conv1_sub1"), s));
+        EACH(launch_conv_first(q.x, x_is_u8, q.n, h, w, net->c_in, 1, c.w, c.scale, c.shift, q.A("conv1_sub1"), q.s));
     }
-    HIP_RET(run_conv(net, "conv2_sub1", A("conv1_sub1"), n, h / 2, w / 2, nullptr, true, false, A("conv2_sub1"), s));
-    HIP_RET(run_conv(net, "conv3_sub1", A("conv2_sub1"), n, h / 4, w / 4, nullptr, true, false, A("conv3_sub1"), s));
+    EACH(run_conv(net, "conv2_sub1", q.A("conv1_sub1"), q.n, h / 2, w / 2, nullptr, true, false, q.A("conv2_sub1"), q.s));
+    EACH(run_conv(net, "conv3_sub1", q.A("conv2_sub1"), q.n, h / 4, w / 4, nullptr, true, false, q.A("conv3_sub1"), q.s));
     // ---- cascade feature fusion (section 4): the 2x interpolations are evaluated inside the dilated convs ----
-    HIP_RET(run_conv(net, "conv3_1_sub2_proj", A("conv3_1"), n, h / 16, w / 16, nullptr, false, false,
-                     A("conv3_1_sub2_proj"), s));
-    HIP_RET(run_conv(net, "conv_sub4", A("conv5_4_k1"), n, h / 32, w / 32, A("conv3_1_sub2_proj"), true, true,
-                     A("sub24_sum"), s));
-    HIP_RET(run_conv(net, "conv3_sub1_proj", A("conv3_sub1"), n, h / 8, w / 8, nullptr, false, false,
-                     A("conv3_sub1_proj"), s));
-    HIP_RET(run_conv(net, "conv_sub2", A("sub24_sum"), n, h / 16, w / 16, A("conv3_sub1_proj"), true, true,
-                     A("sub12_sum"), s));
+    EACH(run_conv(net, "conv3_1_sub2_proj", q.A("conv3_1"), q.n, h / 16, w / 16, nullptr, false, false,
+                  q.A("conv3_1_sub2_proj"), q.s));
+    EACH(run_conv(net, "conv_sub4", q.A("conv5_4_k1"), q.n, h / 32, w / 32, q.A("conv3_1_sub2_proj"), true, true,
+                  q.A("sub24_sum"), q.s));
+    EACH(run_conv(net, "conv3_sub1_proj", q.A("conv3_sub1"), q.n, h / 8, w / 8, nullptr, false, false,
+                  q.A("conv3_sub1_proj"), q.s));
+    EACH(run_conv(net, "conv_sub2", q.A("sub24_sum"), q.n, h / 16, w / 16, q.A("conv3_sub1_proj"), true, true,
+                  q.A("sub12_sum"), q.s));
     // sub12_sum_interp (2x) + conv6_cls (1x1, bias)
-    HIP_RET(run_conv(net, "conv6_cls", A("sub12_sum"), n, h / 8, w / 8, nullptr, false, true, A("conv6_cls"), s));
+    EACH(run_conv(net, "conv6_cls", q.A("sub12_sum"), q.n, h / 8, w / 8, nullptr, false, true, q.A("conv6_cls"), q.s));
+#undef EACH
     return hipSuccess;
 }
 
@@ -302,7 +320,9 @@ int forward_any(ssal_icnet *net, const void *x_dev, bool u8, int n, int h, int w
     IcWorkspace W = carve(net, ws_dev, ws_bytes, n, h, w);
     if (!W.ok) return fail(SSAL_ENOMEM, "workspace too small: need %lld bytes, got %lld", (long long)W.bytes, (long long)ws_bytes);
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(run_trunk(net, x_dev, u8, n, h, w, W, s, false));
+    std::vector<Grp> one(1);
+    one[0] = {W, x_dev, n, s};
+    HIP_TRY(run_trunk(net, one, u8, h, w, false));
     HIP_TRY(launch_resize_bilinear(W.act.at("conv6_cls"), n, h / 4, w / 4, net->classes, h, w, logits_dev, s));
     return SSAL_OK;
 }
@@ -320,9 +340,48 @@ int score_any(ssal_icnet *net, const void *x_dev, bool u8, int n, int h, int w, 
     IcWorkspace W = carve(net, ws_dev, ws_bytes, n, h, w);
     if (!W.ok) return fail(SSAL_ENOMEM, "workspace too small: need %lld bytes, got %lld", (long long)W.bytes, (long long)ws_bytes);
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(run_trunk(net, x_dev, u8, n, h, w, W, s, true));
-    HIP_TRY(launch_upscore(W.act.at("conv6_cls"), n, h / 4, w / 4, net->classes, measure, threshold, W.partial,
-                           label_dev, mask_dev, conf_dev, s));
+    // image-group schedule (same knob and same reasoning as ENet's run_net, ssal_api.hip): the batch runs as G chains of
+    // ~n / G images on library-owned side streams, forked from / joined into the caller's stream with events
+    int G = ssal::knobs().img_groups;
+    if (G < 2 || G > 8 || n < G || ssal::prof_enabled()) G = 1;
+    const int64_t px = (int64_t)h * w, ppm_img = ppm_scratch_floats(1, h / 32, 1024);
+    const int blocks = upscore_blocks(h / 4, w / 4);
+    std::vector<Grp> grp(G);
+    std::vector<int64_t> first(G + 1);
+    for (int g = 0; g <= G; ++g) first[g] = (int64_t)g * n / G;
+    if (G > 1) {
+        if (!net->fork_ev) HIP_TRY(hipEventCreateWithFlags(&net->fork_ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(net->fork_ev, s));
+    }
+    for (int g = 0; g < G; ++g) {
+        const int64_t i0 = first[g];
+        Grp &q = grp[g];
+        q.W = W;
+        for (const ActSpec &a : net->acts) q.W.act[a.name] = W.act.at(a.name) + i0 * (h / a.div) * (w / a.div) * a.c;
+        q.W.pooled = W.pooled + i0 * ppm_img;
+        q.W.partial = W.partial + i0 * blocks;
+        q.x = (const char *)x_dev + (size_t)i0 * px * net->c_in * (u8 ? 1 : 4);
+        q.n = (int)(first[g + 1] - i0);
+        q.s = s;
+        if (G > 1) {
+            if (!net->side[g]) HIP_TRY(ssal::side_stream(g, &net->side[g]));
+            if (!net->join_ev[g]) HIP_TRY(hipEventCreateWithFlags(&net->join_ev[g], hipEventDisableTiming));
+            q.s = net->side[g];
+            HIP_TRY(hipStreamWaitEvent(q.s, net->fork_ev, 0));
+        }
+    }
+    HIP_TRY(run_trunk(net, grp, u8, h, w, true));
+    for (int g = 0; g < G; ++g) {
+        const Grp &q = grp[g];
+        const int64_t i0 = first[g];
+        HIP_TRY(launch_upscore(q.A("conv6_cls"), q.n, h / 4, w / 4, net->classes, measure, threshold, q.W.partial,
+                               label_dev ? label_dev + i0 * px : nullptr, mask_dev ? mask_dev + i0 * px : nullptr,
+                               conf_dev ? conf_dev + i0 * px : nullptr, q.s));
+        if (G > 1) {
+            HIP_TRY(hipEventRecord(net->join_ev[g], q.s));
+            HIP_TRY(hipStreamWaitEvent(s, net->join_ev[g], 0));
+        }
+    }
     HIP_TRY(launch_reduce_mean(W.partial, n, upscore_blocks(h / 4, w / 4), (double)h * (double)w, scores_dev, s));
     return SSAL_OK;
 }
@@ -365,6 +424,9 @@ SSAL_API int ssal_icnet_destroy(ssal_icnet *net)
 {
     if (!net) return SSAL_OK;
     if (net->arena) (void)hipFree(net->arena);
+    for (int g = 0; g < 8; ++g)
+        if (net->join_ev[g]) (void)hipEventDestroy(net->join_ev[g]);
+    if (net->fork_ev) (void)hipEventDestroy(net->fork_ev);
     delete net;
     return SSAL_OK;
 }

@@ -106,12 +106,17 @@ hipError_t launch_upsample_mfma(const float *x, float *y, const uint8_t *code, i
 struct Knobs {
     int bnk_tw;      // 16 = force 8x16 tiles in the 128-channel bottleneck kernels
     int bnk_xcd;     // 1 = XCD-aware tile order in the 128-channel bottleneck kernels
-    int img_groups;  // stage 2 + 3 of ENet: the batch runs as this many image groups on side streams (default 2; 1 = everything on the caller's stream)
+    int img_span;    // which layers run in image groups: 0 = Bottleneck2_1..3_8, 1 = + 2_0, 2 = 1_0..5_1, 3 = Initial..5_1, 4 = Initial..Final + score (default)
+    int img_groups;  // ENet: the layers of img_span run as this many image groups on side streams (default 2; 1 = everything on the caller's stream)
 #ifdef SSAL_MEASURE
     int ablate;      // measurement builds only: 1 = stop after the projection phase, 2 = skip it (results invalid)
 #endif
 };
 Knobs &knobs();
+// side stream g (0..7) of the image-group schedule: ONE process-wide pool shared by every handle (created on first use,
+// never destroyed).  Per-handle streams would exhaust the hardware queues of the process: with four or more user streams
+// alive two chains share a queue and the second model scored in a process ran 14 % slower.
+hipError_t side_stream(int g, hipStream_t *out);
 
 // phase-trace buffer the bottleneck launchers hand to their kernels (ssal_debug_set_trace; NULL = off)
 extern unsigned long long *g_trace_buf;

@@ -905,16 +905,17 @@ def test_spatial_dropout_op():
 
 
 def test_image_group_streams_are_bit_identical(enet_c3k19):
-    """stages 2 + 3 run as `img_groups` image chains on library-owned side streams (default 2): logits, labels and scores
-    must not depend on the grouping (1 = caller's stream only, 2, 4; a batch the group count does not divide falls back
-    to one stream), and back-to-back calls on the same workspace must not race (the join precedes stage 4)"""
+    """the network runs as `img_groups` image chains on library-owned side streams (default: 2 chains over Initial .. Final +
+    score): logits, labels and scores must not depend on the grouping (1 = caller's stream only, 2, 4; uneven groups for a
+    batch of 3) nor on the span of layers that is grouped, and back-to-back calls on one workspace must not race"""
     net, _ = enet_c3k19
     x = syn.synth_frames_device(40, 4, 128, 256, 3)
     x3 = syn.synth_frames_device(40, 3, 128, 256, 3)
     ref = None
     try:
-        for g in (1, 2, 4):
+        for g, span in ((1, 4), (2, 4), (4, 4), (2, 0), (2, 2), (3, 3)):
             _lib.set_knob("img_groups", g)
+            _lib.set_knob("img_span", span)
             outs = []
             for _ in range(3):
                 s, e = net.score(x, "entropy", return_label=True)
@@ -924,9 +925,10 @@ def test_image_group_streams_are_bit_identical(enet_c3k19):
                 assert all(np.array_equal(a, b) for a, b in zip(o, outs[0]))
             if ref is None:
                 ref = outs[0]
-            assert all(np.array_equal(a, b) for a, b in zip(outs[0], ref)), "img_groups=%d changes the result" % g
+            assert all(np.array_equal(a, b) for a, b in zip(outs[0], ref)), "img_groups=%d span=%d changes the result" % (g, span)
     finally:
         _lib.set_knob("img_groups", 2)
+        _lib.set_knob("img_span", 4)
     assert _lib.get_knobs()["defaults"] == 1
 
 

@@ -370,3 +370,24 @@ def test_repeated_scoring_is_bitwise_stable_at_bench_tile_counts(icnet19):
     for _ in range(24):
         s, e = net.score(x, "margin", return_label=True, return_confidence=True)
         assert torch.equal(s, s0) and torch.equal(e["label"], l0) and torch.equal(e["confidence"], c0)
+
+
+def test_image_group_streams_are_bit_identical(icnet19):
+    """the score path runs as `img_groups` image chains on library-owned side streams (default 2): scores and labels
+    must not depend on the grouping (1, 2, 3 with uneven groups), also for a batch of one"""
+    from semanticsegmentationactivelearning_amd import _lib
+    net, _ = icnet19
+    x = syn.synth_frames_device(7, 4, 64, 128, 3)
+    ref = None
+    try:
+        for g in (1, 2, 3):
+            _lib.set_knob("img_groups", g)
+            outs = []
+            for _ in range(2):
+                s, e = net.score(x, "margin", return_label=True)
+                outs.append((s.cpu().numpy(), e["label"].cpu().numpy(), net.score(x[:1], "margin").cpu().numpy()))
+            assert all(np.array_equal(a, b) for a, b in zip(outs[0], outs[1]))
+            ref = ref or outs[0]
+            assert all(np.array_equal(a, b) for a, b in zip(outs[0], ref)), "img_groups=%d changes the result" % g
+    finally:
+        _lib.set_knob("img_groups", 2)

@@ -6,7 +6,9 @@ MODEL=${1:-enet}
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python3 bench.py --model $MODEL --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-roofline"
+# img_groups=1: whole-batch launches on one stream, the launch shape bench.py's roofline leg times (ssal_profile_enable
+# serialises the image groups); per-launch traffic of the default two-chain schedule would be that of half-batch launches
+CMD="python3 bench.py --model $MODEL --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-roofline --knob img_groups=1 --allow-nondefault-knobs"
 run() { # name counters...
     local name=$1; shift
     echo "=== pmc $MODEL $name: $*" | tee -a $OUT/pmc_summary.log

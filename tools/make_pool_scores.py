@@ -4,8 +4,8 @@ GPU box:  python tools/make_pool_scores.py   ->  gpurun_out/pool_scores.npz   (c
 
 Keys (bench.table_key): <model>_c<channels>k<classes>_<H>x<W>_<measure>_seed<weights seed>
   enet_c3k19_1024x2048_entropy_seed0   all 2975 frames of the synthetic pool   (BASELINE configs[1] / [2])
-  icnet_c3k19_1024x2048_margin_seed0   frames 0..255                           (configs[3])
-  enet_c4k6_1024x2048_entropy_seed1    frames 0..255                           (configs[4])
+  icnet_c3k19_1024x2048_margin_seed0   all 2975 frames                        (configs[3])
+  enet_c4k6_1024x2048_entropy_seed1    all 2975 frames                        (configs[4])
 The scores are per-image float64 means produced by the HIP path (bitwise reproducible, independent of the batch
 composition: tests/test_gpu_parity.py::test_score_is_bitwise_reproducible).  What ties the table to the oracle: the
 full-resolution parity tests (test_full_resolution_image_bit_exact, test_full_resolution_c5_rgb_nir_frame_bit_exact,
@@ -23,8 +23,8 @@ from semanticsegmentationactivelearning_amd import synthetic as syn
 
 H, W, BS = 1024, 2048, 8
 out = {}
-for model, c, k, measure, seed, count in (("enet", 3, 19, "entropy", 0, bench.POOL), ("icnet", 3, 19, "margin", 0, 256),
-                                          ("enet", 4, 6, "entropy", 1, 256)):
+for model, c, k, measure, seed, count in (("enet", 3, 19, "entropy", 0, bench.POOL), ("icnet", 3, 19, "margin", 0, bench.POOL),
+                                          ("enet", 4, 6, "entropy", 1, bench.POOL)):
     net = ssal.ICNet(k) if model == "icnet" else ssal.ENet(k)
     net.build((None, None, None, c))
     (syn.randomize_icnet if model == "icnet" else syn.randomize_enet)(net, seed=seed)

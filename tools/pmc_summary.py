@@ -8,7 +8,7 @@ import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out")
 MODEL = sys.argv[1] if len(sys.argv) > 1 else "enet"
-ROUND = sys.argv[2] if len(sys.argv) > 2 else "r02"
+ROUND = sys.argv[2] if len(sys.argv) > 2 else "r03"
 DST = os.path.join(ROOT, "profiles", "%s_pmc" % ROUND)
 os.makedirs(DST, exist_ok=True)
 

@@ -647,7 +647,16 @@ hipError_t run_layer_idx(const ssal_enet *net, int li, const void *x, bool x_is_
                          int w, hipStream_t s)
 {
     const DevLayer &L = net->layers[li];
-    if (li == 0) return launch_initial(x, x_is_u8, n, h, w, net->c_in, L.w, L.scale, L.shift, L.alpha, V.a0, s);
+    // Initial + Bottleneck1_0 in one launch: Initial's output (a0; no endpoint) is never written
+    const bool fuse01 = (ssal::knobs().fuse_ends & 1) && g_use_mfma && initial_down16_supported(net->c_in) &&
+                        (long)h * w * 16 < (1L << 31);
+    if (li == 0) return fuse01 ? hipSuccess : launch_initial(x, x_is_u8, n, h, w, net->c_in, L.w, L.scale, L.shift, L.alpha, V.a0, s);
+    if (li == 1 && fuse01) {
+        const DevLayer &I = net->layers[0];
+        return launch_initial_down16(x, x_is_u8, n, h, w, net->c_in, I.w, I.scale, I.shift, I.alpha, V.s1a, V.code1,
+                                     L.proj_w, L.proj_scale, L.proj_shift, L.proj_alpha, L.conv_w, L.conv_scale, L.conv_shift,
+                                     L.conv_alpha, L.exp_w, L.exp_scale, L.exp_shift, L.res_alpha, s);
+    }
     if (li == 1) return run_down(L, V.a0, n, h / 2, w / 2, V.s1a, V.code1, V.T, s);
     if (li <= 5) return run_regular(L, (li - 2) % 2 == 0 ? V.s1a : V.s1b, n, h / 4, w / 4, (li - 2) % 2 == 0 ? V.s1b : V.s1a, V.T, s);
     if (li == 6) return run_down(L, V.s1a, n, h / 4, w / 4, V.s2a, V.code2, V.T, s);
@@ -1213,6 +1222,7 @@ SSAL_API int ssal_debug_set_knob(const char *name, int value)
     else if (n == "bnk_xcd") k.bnk_xcd = value;
     else if (n == "img_groups") k.img_groups = value;
     else if (n == "img_span") k.img_span = value;
+    else if (n == "fuse_ends") k.fuse_ends = value;
 #ifdef SSAL_MEASURE
     else if (n == "ablate") k.ablate = value;
 #endif
@@ -1224,18 +1234,18 @@ SSAL_API int ssal_debug_set_knob(const char *name, int value)
 // refuses to time a library whose knobs are not at their defaults
 SSAL_API int ssal_debug_get_knobs(char *json_out, int64_t cap)
 {
-    if (!json_out || cap < 200) return fail(SSAL_EINVAL, "json_out too small");
+    if (!json_out || cap < 240) return fail(SSAL_EINVAL, "json_out too small");
     const ssal::Knobs &k = ssal::knobs();
     int measure = 0, ablate = 0;
 #ifdef SSAL_MEASURE
     measure = 1;
     ablate = k.ablate;
 #endif
-    const int dflt = g_use_mfma && k.bnk_tw == 0 && k.bnk_xcd == 1 && k.img_groups == 2 && k.img_span == 4 && ablate == 0 && !ssal::prof_enabled()
+    const int dflt = g_use_mfma && k.bnk_tw == 0 && k.bnk_xcd == 1 && k.img_groups == 2 && k.img_span == 4 && k.fuse_ends == 1 && ablate == 0 && !ssal::prof_enabled()
                      && ssal::g_trace_buf == nullptr;
-    snprintf(json_out, (size_t)cap, "{\"kernel_family\": %d, \"bnk_tw\": %d, \"bnk_xcd\": %d, \"img_groups\": %d, \"img_span\": %d, "
+    snprintf(json_out, (size_t)cap, "{\"kernel_family\": %d, \"bnk_tw\": %d, \"bnk_xcd\": %d, \"img_groups\": %d, \"img_span\": %d, \"fuse_ends\": %d, "
              "\"ablate\": %d, \"measure_build\": %d, \"profiling\": %d, \"defaults\": %d}", g_use_mfma ? 1 : 0,
-             k.bnk_tw, k.bnk_xcd, k.img_groups, k.img_span, ablate, measure, ssal::prof_enabled() ? 1 : 0, dflt);
+             k.bnk_tw, k.bnk_xcd, k.img_groups, k.img_span, k.fuse_ends, ablate, measure, ssal::prof_enabled() ? 1 : 0, dflt);
     return SSAL_OK;
 }
 

@@ -448,6 +448,261 @@ __global__ __launch_bounds__(256, 3) void k_downsample16(DownArgs a)
 }
 
 // =================================================================================================
+// Initial block + Bottleneck1_0 in ONE launch (enet_modules.py:190-224 + 868-938).
+// Unfused, the Initial kernel writes its [N,H/2,W/2,16] output (268 MB at batch 8 x 1024 x 2048) and k_downsample16
+// reads it back at once: both launches are HBM-bound.  Here a workgroup owns an 8 x 16 tile of Bottleneck1_0's OUTPUT:
+//   phase 0  the 41 x 73 image window behind the halo'd tile -> LDS (coalesced rows; uint8 frames converted on the way,
+//            x * (1/255) as tf.image.convert_image_dtype); the expansion BN vectors -> LDS
+//   phase A  per 16-pixel M-tile, lane (pixel, quarter g) EVALUATES the four 2x2-patch fragments the projection needs --
+//            Initial's output channels 4g..4g+3 at the four patch positions: conv 3x3/s2 on the matrix cores, one exact fmaf
+//            chain per channel over (kh, kw, ci) ascending (the order of k_initial and of the oracle; window taps outside
+//            the image are exact zeros), 2x2 max-pool of the image for the concatenated channels, BN + PReLU -- instead of
+//            loading them;
+//            from there on the kernel IS k_downsample16: projection GEMM (K = 4 taps x 16), first-max pooling of the
+//            patch + packed window codes, halo ring, P in LDS
+//   phase B  unchanged: 3x3 conv (8 -> 8), expansion (8 -> 64) + pooled residual + PReLU, float4 stores.
+// Initial's output never exists (it is no endpoint: enet.py:311-318); the per-layer entry points keep the two kernels.
+// The halo recompute of Initial is 720 / 512 = 1.41x of a 351-FMA-per-pixel convolution (7 MFMAs per 16 pixels).
+// =================================================================================================
+struct InitDownArgs {
+    const void *img;                                // [N,H,W,CIN] float32 in [0,1] or the decoded uint8 frame
+    const float *iw, *iscale, *ishift, *ialpha;     // Initial: kernel [3][3][CIN][16-CIN], folded BN [16], alpha [16]
+    DownArgs d;                                     // Bottleneck1_0: d.x unused, d.H / d.W = Initial's output dims
+};
+
+__device__ __forceinline__ float unit_of(float v) { return v; }
+__device__ __forceinline__ float unit_of(uint8_t v) { return (float)v * (1.0f / 255.0f); }
+
+template <int CIN, typename TX>
+__global__ __launch_bounds__(256, 3) void k_initial_down16(InitDownArgs A)
+{
+    constexpr int TW = 16, TH = 8, CI = 16, FF = 8, CO = 64, PS = FF + 2, HW2 = TW + 2;
+    constexpr int CC = 16 - CIN;               // convolution channels of Initial; channels CC..15 = pooled image
+    constexpr int MPW = (TH * TW) / 16 / 4;    // centre M-tiles per wave: 2
+    constexpr int RING = 2 * HW2 + 2 * TH;     // halo ring pixels: 52 = 4 M-tiles, one per wave
+    constexpr int WR = 4 * (TH + 2) + 1, WC = 4 * (TW + 2) + 1, WCF = WC * CIN;  // image window: 41 rows x 73 pixels
+    constexpr int PROWS = 192;                 // >= (TH+2)*(TW+2) = 180
+    __shared__ float IMG[WR * WCF];
+    __shared__ float P[PROWS * PS];
+    __shared__ float BNV[3 * CO];
+    const DownArgs &a = A.d;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int Ho = a.H / 2, Wo = a.W / 2, HI = 2 * a.H, WIM = 2 * a.W;
+    int b = blockIdx.x;
+    const int tx = b % a.tiles_x; b /= a.tiles_x;
+    const int ty = b % a.tiles_y; b /= a.tiles_y;
+    const int n = b;
+    const int ty0 = ty * TH, tx0 = tx * TW;
+    float *yimg = a.y + (long)n * Ho * Wo * CO;
+    uint8_t *cimg = a.code + (long)n * Ho * Wo * CI;
+
+    // ---- phase 0 ---------------------------------------------------------------------------------------
+    {
+        const TX *ximg = reinterpret_cast<const TX *>(A.img) + (long)n * HI * WIM * CIN;
+        const int r0 = 4 * ty0 - 4, cf0 = (4 * tx0 - 4) * CIN;
+        // every load of the thread is requested before the first one is used (a rolled load -> store loop exposes the
+        // memory latency once per element: 36 round trips per workgroup); (row, offset) advance by constants
+        constexpr int NIT = (WR * WCF + 255) / 256;
+        float tmp[NIT];
+        int wr = (int)threadIdx.x / WCF, wf = (int)threadIdx.x % WCF;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int gy = r0 + wr, gf = cf0 + wf;
+            const bool ok = wr < WR && gy >= 0 && gy < HI && gf >= 0 && gf < WIM * CIN;
+            tmp[it] = unit_of(ximg[ok ? (long)gy * WIM * CIN + gf : 0]);
+            tmp[it] = ok ? tmp[it] : 0.0f;
+            wr += 256 / WCF; wf += 256 % WCF;
+            if (wf >= WCF) { wf -= WCF; ++wr; }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = (int)threadIdx.x + 256 * it;
+            if (idx < WR * WCF) IMG[idx] = tmp[it];
+        }
+        if (threadIdx.x < 3 * CO / 4) {
+            const int arr = threadIdx.x / (CO / 4), k4 = threadIdx.x % (CO / 4);
+            const float *src = arr == 0 ? a.es : arr == 1 ? a.et : a.ra;
+            reinterpret_cast<float4 *>(BNV)[threadIdx.x] = reinterpret_cast<const float4 *>(src)[k4];
+        }
+    }
+    const bool cval = i16 < FF;
+    const int ic = cval ? i16 : 0;
+    float wpr[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {  // step s = 4*tap + s': ci = 4s' + g of tap (dy,dx)
+        const float w = a.wp[((s >> 2) * CI + 4 * (s & 3) + g) * FF + ic];
+        wpr[s] = cval ? w : 0.0f;
+    }
+    const float bs = a.ps[ic], bt = a.pt[ic], ba = a.pa[ic];
+    const float4 isc = *reinterpret_cast<const float4 *>(A.iscale + 4 * g);
+    const float4 ish = *reinterpret_cast<const float4 *>(A.ishift + 4 * g);
+    const float4 ial = *reinterpret_cast<const float4 *>(A.ialpha + 4 * g);
+    __syncthreads();
+
+    // ---- phase A ---------------------------------------------------------------------------------------
+    auto q_center = [&](int t) { return (t / TW + 1) * HW2 + (t % TW) + 1; };
+    auto q_ring = [&](int u) {
+        if (u < HW2) return u;
+        if (u < 2 * HW2) return (TH + 1) * HW2 + (u - HW2);
+        const int k = u - 2 * HW2;
+        return (1 + (k >> 1)) * HW2 + ((k & 1) ? HW2 - 1 : 0);
+    };
+    // Initial's convolution on the matrix cores (the fp32 MFMA rate equals the packed-FMA rate, but the operands need no
+    // per-lane broadcast copies): D[co][pixel] = W^T[co][k] * X[k][pixel], k = (kh, kw, ci) ascending = the fmaf-chain
+    // order of k_initial and of the oracle; K = 9*CIN padded to a multiple of 4 with zero kernel rows.  A operand: the
+    // kernel, row co = i16 (zero rows for the pooled channels), k = 4s + g -- NS registers, loop-invariant.  B operand:
+    // lane (pixel i16, k = 4s + g) reads ITS tap of the pixel's 3x3 window straight from the LDS image.
+    constexpr int NS = (9 * CIN + 3) / 4;
+    float wI[NS];
+    int koff[NS];
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) {
+        const int k = 4 * s_ + g;
+        const bool kv = k < 9 * CIN;
+        const float w = A.iw[(kv ? k : 0) * CC + (i16 < CC ? i16 : 0)];
+        wI[s_] = (kv && i16 < CC) ? w : 0.0f;
+        koff[s_] = kv ? (k / (3 * CIN)) * WCF + (k % (3 * CIN)) : 0;  // (kw, ci) are contiguous inside a window row
+    }
+    // Initial's output channels 4g..4g+3 at the 2x2 patch of halo'd-tile pixel q (row hr, column hc): v[tap], tap = dy*2+dx
+    auto eval_patch = [&](int q, float4 (&v)[4]) {
+        const int hr = q / HW2, hc = q - hr * HW2;
+        const float *wp0 = IMG + (4 * hr) * WCF + (4 * hc) * CIN;  // 5 x 5 pixel window of the image
+        const float scv[4] = {isc.x, isc.y, isc.z, isc.w}, shv[4] = {ish.x, ish.y, ish.z, ish.w},
+                    alv[4] = {ial.x, ial.y, ial.z, ial.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float *wt = wp0 + (2 * (t >> 1)) * WCF + (2 * (t & 1)) * CIN;  // window of Initial pixel (2y+dy, 2x+dx)
+            f32x4 acc = {0};
+#pragma unroll
+            for (int s_ = 0; s_ < NS; ++s_) acc = mfma16(wI[s_], wt[koff[s_]], acc);
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float val = acc[r];
+                if (12 + r >= CC) {  // channels >= CC (quarter 3 only): 2x2 max-pool of the image (k_initial scans the window
+                    const int ci = 12 + r - CC;  // with a strict '>': the VALUE of the first maximum is the maximum)
+                    const float bv = fmaxf(fmaxf(wt[ci], wt[CIN + ci]), fmaxf(wt[WCF + ci], wt[WCF + CIN + ci]));
+                    val = g == 3 ? bv : val;
+                }
+                o[r] = prelu1(fmaf(val, scv[r], shv[r]), alv[r]);
+            }
+            v[t] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    };
+    auto project = [&](const float4 (&v)[4], unsigned vmask, const int (&qrow)[4]) {
+        f32x4 acc = {0};
+#pragma unroll
+        for (int tap = 0; tap < 4; ++tap) {
+            float r0 = v[tap].x, r1 = v[tap].y, r2 = v[tap].z, r3 = v[tap].w;
+            transpose4(r0, r1, r2, r3);
+            acc = mfma16(r0, wpr[4 * tap + 0], acc);
+            acc = mfma16(r1, wpr[4 * tap + 1], acc);
+            acc = mfma16(r2, wpr[4 * tap + 2], acc);
+            acc = mfma16(r3, wpr[4 * tap + 3], acc);
+        }
+        if (cval) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = (vmask >> (4 * g + r)) & 1u;
+                if (qrow[r] >= 0) P[qrow[r] * PS + i16] = ok ? prelu1(fmaf(acc[r], bs, bt), ba) : 0.0f;
+            }
+        }
+    };
+
+    float4 pooled[MPW];
+    long opixk[MPW];
+#pragma unroll
+    for (int k = 0; k < MPW; ++k) {
+        const int mt = wave + 4 * k;
+        const int t = mt * 16 + i16;
+        const int oy = ty0 + t / TW, ox = tx0 + t % TW;
+        const bool valid = (oy < Ho) && (ox < Wo);
+        opixk[k] = valid ? (long)oy * Wo + ox : -1;
+        float4 vk[4];
+        eval_patch(q_center(t), vk);
+        const unsigned vmask = (unsigned)(__ballot(valid) & 0xFFFFull);
+        int qrow[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) qrow[r] = q_center(mt * 16 + 4 * g + r);
+        project(vk, vmask, qrow);
+        // 2x2 window, strict '>' scan in (dy,dx) order: the first maximum wins (TF's rule)
+        const float c00[4] = {vk[0].x, vk[0].y, vk[0].z, vk[0].w};
+        const float c01[4] = {vk[1].x, vk[1].y, vk[1].z, vk[1].w};
+        const float c10[4] = {vk[2].x, vk[2].y, vk[2].z, vk[2].w};
+        const float c11[4] = {vk[3].x, vk[3].y, vk[3].z, vk[3].w};
+        float best[4];
+        unsigned packed = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float bv = c00[r];
+            unsigned cd = 0;
+            if (c01[r] > bv) { bv = c01[r]; cd = 1; }
+            if (c10[r] > bv) { bv = c10[r]; cd = 2; }
+            if (c11[r] > bv) { bv = c11[r]; cd = 3; }
+            best[r] = bv;
+            packed |= cd << (8 * r);
+        }
+        pooled[k] = make_float4(best[0], best[1], best[2], best[3]);
+        if (valid) *reinterpret_cast<unsigned *>(cimg + opixk[k] * CI + 4 * g) = packed;  // channels 4g..4g+3
+    }
+    {  // halo ring: M-tile `wave` of the 52 ring pixels
+        const int u = wave * 16 + i16;
+        const int q = u < RING ? q_ring(u) : 0;
+        const int pr = ty0 - 1 + q / HW2, pc = tx0 - 1 + q % HW2;
+        const bool rvalid = (u < RING) && (pr >= 0) && (pr < Ho) && (pc >= 0) && (pc < Wo);
+        float4 vr[4];
+        eval_patch(q, vr);
+        const unsigned vmask = (unsigned)(__ballot(rvalid) & 0xFFFFull);
+        int qrow[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ur = wave * 16 + 4 * g + r;
+            qrow[r] = ur < RING ? q_ring(ur) : -1;
+        }
+        project(vr, vmask, qrow);
+    }
+
+    // loop-invariant operands of phase B, requested before the barrier
+    float wcr[9 * (FF / 4)];
+    load_conv16_weights<FF>(a, i16, g, wcr);
+    float cs[4], ct[4], ca[4];
+    load_conv16_bn<FF>(a, g, cs, ct, ca);
+    float wer[(CO / 16) * 2];
+#pragma unroll
+    for (int nt = 0; nt < CO / 16; ++nt) {
+        wer[nt * 2 + 0] = a.we[(0 + g) * CO + nt * 16 + i16];
+        wer[nt * 2 + 1] = a.we[(4 + g) * CO + nt * 16 + i16];
+    }
+    __syncthreads();
+
+    // ---- phase B: as k_downsample16 ----------------------------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < MPW; ++k) {
+        const int mt = wave + 4 * k;
+        float q[4];
+        conv16_tile_q<TW, FF>(P, wcr, cs, ct, ca, mt, i16, g, q);
+#pragma unroll
+        for (int nt = 0; nt < CO / 16; ++nt) {
+            f32x4 e = {0};
+            e = mfma16(wer[nt * 2 + 0], q[0], e);
+            e = mfma16(wer[nt * 2 + 1], q[1], e);
+            const int co = nt * 16 + 4 * g;  // reg r = channel co + r
+            const float4 s1 = *reinterpret_cast<const float4 *>(BNV + co);
+            const float4 t1 = *reinterpret_cast<const float4 *>(BNV + CO + co);
+            const float4 al = *reinterpret_cast<const float4 *>(BNV + 2 * CO + co);
+            const float4 rr4 = nt == 0 ? pooled[k] : make_float4(0.f, 0.f, 0.f, 0.f);  // channels >= 16: zero padding
+            float4 o;
+            o.x = prelu1(fmaf(e[0], s1.x, t1.x) + rr4.x, al.x);
+            o.y = prelu1(fmaf(e[1], s1.y, t1.y) + rr4.y, al.y);
+            o.z = prelu1(fmaf(e[2], s1.z, t1.z) + rr4.z, al.z);
+            o.w = prelu1(fmaf(e[3], s1.w, t1.w) + rr4.w, al.w);
+            if (opixk[k] >= 0) *reinterpret_cast<float4 *>(yimg + opixk[k] * CO + co) = o;
+        }
+    }
+}
+
+// =================================================================================================
 // upsample bottleneck 64 -> 16 (Bottleneck5_0; enet_modules.py:1217-1292): proj 64 -> 16, transposed
 // conv 16 -> 8 with two output-parity classes stacked in the 16 MFMA rows ([ee|eo] and [oe|oo], see
 // ssal_bottleneck_mfma.hip), exp 8 -> 16, residual 1x1 conv 64 -> 16 + gather-unpool.
@@ -692,6 +947,45 @@ hipError_t launch_downsample_mfma16(const DownArgs &a0, hipStream_t s)
                    4.0 * (4.0 * opix * 16 + opix * 64) + opix * 16, s);
     if (wide) hipLaunchKernelGGL(k_downsample16<32>, dim3((unsigned)grid), dim3(256), 0, s, a);
     else      hipLaunchKernelGGL(k_downsample16<16>, dim3((unsigned)grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+bool initial_down16_supported(int c_in) { return c_in == 1 || c_in == 3 || c_in == 4; }
+
+// Initial + Bottleneck1_0 (H, W = IMAGE dims, divisible by 4)
+hipError_t launch_initial_down16(const void *img, bool img_is_u8, int N, int H, int W, int c_in, const float *iw,
+                                 const float *iscale, const float *ishift, const float *ialpha, float *y, uint8_t *code,
+                                 const float *wp, const float *ps, const float *pt, const float *pa, const float *wc,
+                                 const float *cs, const float *ct, const float *ca, const float *we, const float *es,
+                                 const float *et, const float *ra, hipStream_t s)
+{
+    if (H % 4 || W % 4 || !initial_down16_supported(c_in)) return hipErrorInvalidValue;
+    InitDownArgs A;
+    A.img = img; A.iw = iw; A.iscale = iscale; A.ishift = ishift; A.ialpha = ialpha;
+    A.d.x = nullptr; A.d.y = y; A.d.code = code;
+    A.d.wp = wp; A.d.ps = ps; A.d.pt = pt; A.d.pa = pa;
+    A.d.wc = wc; A.d.cs = cs; A.d.ct = ct; A.d.ca = ca;
+    A.d.we = we; A.d.es = es; A.d.et = et; A.d.ra = ra;
+    A.d.N = N; A.d.H = H / 2; A.d.W = W / 2;
+    A.d.TH = 8;
+    const int Ho = H / 4, Wo = W / 4;
+    A.d.tiles_y = (Ho + 7) / 8;
+    A.d.tiles_x = (Wo + 15) / 16;
+    A.d.trace = nullptr;
+    const long grid = (long)N * A.d.tiles_y * A.d.tiles_x;
+    if (grid <= 0 || grid > 0x7fffffffL) return hipErrorInvalidValue;
+    const double ipix = (double)N * (H / 2) * (W / 2), opix = (double)N * Ho * Wo;
+    ProfScope prof("k_initial_down16",
+                   2.0 * ipix * 9 * c_in * (16 - c_in) + 2.0 * opix * (4.0 * 16 * 8 + 9.0 * 8 * 8 + 8.0 * 64),
+                   (img_is_u8 ? 1.0 : 4.0) * N * (double)H * W * c_in + 4.0 * opix * 64 + opix * 16, s);
+    dim3 G((unsigned)grid), B(256);
+#define SSAL_ID16(CINV)                                                                                      \
+    if (img_is_u8) hipLaunchKernelGGL((k_initial_down16<CINV, uint8_t>), G, B, 0, s, A);                      \
+    else           hipLaunchKernelGGL((k_initial_down16<CINV, float>), G, B, 0, s, A)
+    if (c_in == 3) { SSAL_ID16(3); }
+    else if (c_in == 4) { SSAL_ID16(4); }
+    else { SSAL_ID16(1); }
+#undef SSAL_ID16
     return hipGetLastError();
 }
 

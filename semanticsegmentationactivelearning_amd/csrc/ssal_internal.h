@@ -92,6 +92,13 @@ hipError_t launch_downsample_mfma(const float *x, float *y, uint8_t *code, int N
                                   const float *wc, const float *cs, const float *ct, const float *ca,
                                   const float *we, const float *es, const float *et, const float *ra,
                                   hipStream_t s);
+// Initial block + Bottleneck1_0 in one launch (ssal_bottleneck_mfma16.hip: k_initial_down16); H, W = image dims
+bool initial_down16_supported(int c_in);
+hipError_t launch_initial_down16(const void *img, bool img_is_u8, int N, int H, int W, int c_in, const float *iw,
+                                 const float *iscale, const float *ishift, const float *ialpha, float *y, uint8_t *code,
+                                 const float *wp, const float *ps, const float *pt, const float *pa, const float *wc,
+                                 const float *cs, const float *ct, const float *ca, const float *we, const float *es,
+                                 const float *et, const float *ra, hipStream_t s);
 // MFMA-fused upsample bottleneck 128 -> 64 / 64 -> 16 (window-code unpooling); ws = stacked transposed-conv kernel
 bool upsample_mfma_supported(int Cin, int Cout);
 hipError_t launch_upsample_mfma(const float *x, float *y, const uint8_t *code, int N, int H, int W,
@@ -106,6 +113,7 @@ hipError_t launch_upsample_mfma(const float *x, float *y, const uint8_t *code, i
 struct Knobs {
     int bnk_tw;      // 16 = force 8x16 tiles in the 128-channel bottleneck kernels
     int bnk_xcd;     // 1 = XCD-aware tile order in the 128-channel bottleneck kernels
+    int fuse_ends;   // bit 0: Initial + Bottleneck1_0 in one launch (default 1)
     int img_span;    // which layers run in image groups: 0 = Bottleneck2_1..3_8, 1 = + 2_0, 2 = 1_0..5_1, 3 = Initial..5_1, 4 = Initial..Final + score (default)
     int img_groups;  // ENet: the layers of img_span run as this many image groups on side streams (default 2; 1 = everything on the caller's stream)
 #ifdef SSAL_MEASURE

@@ -950,7 +950,7 @@ def test_repeated_calls_do_not_grow_device_memory(enet_c3k19):
 
 def test_knobs_are_reported_and_default():
     k = _lib.get_knobs()
-    assert k["defaults"] == 1 and k["measure_build"] == 0 and k["ablate"] == 0 and "MEASUREMENT" not in k["version"]
+    assert k["defaults"] == 1 and k["measure_build"] == 0 and k["fuse_ends"] == 1 and k["ablate"] == 0 and "MEASUREMENT" not in k["version"]
     with pytest.raises(ValueError):
         _lib.set_knob("ablate", 1)  # no work-skipping switch in the product build
     _lib.set_knob("bnk_tw", 16)

@@ -676,10 +676,25 @@ struct FinalOut {
     float *conf;
 };
 
+// the ranking pass (no logits / label / mask / confidence output) evaluates Bottleneck5_1 inside the Final + score kernel:
+// its output (an endpoint of the FORWARD path only) is neither written nor read
+bool fuse_5_1(const ssal_enet *net, const FinalOut &f)
+{
+    const DevLayer &L = net->layers[27];
+    return (ssal::knobs().fuse_ends & 2) && g_use_mfma && !f.logits && !f.label && !f.mask && !f.conf && L.cin == 16 &&
+           L.f == 4 && L.dil == 1 && !L.asym;
+}
+
 hipError_t run_final(const ssal_enet *net, const NetWorkspace &V, const FinalOut &f, long i0, int n, int h, int w,
                      hipStream_t s)
 {
     const long px = (long)h * w;
+    if (fuse_5_1(net, f)) {
+        const DevLayer &L = net->layers[27];
+        return launch_bnk4_final_score(V.a0, n, h / 2, w / 2, L.proj_w, L.proj_scale, L.proj_shift, L.proj_alpha, L.conv_w,
+                                       L.conv_scale, L.conv_shift, L.conv_alpha, L.exp_w, L.exp_scale, L.exp_shift,
+                                       L.res_alpha, net->layers[kNumLayers - 1].w, net->classes, f.measure, V.partial, s);
+    }
     return launch_final_score(V.a1, n, h / 2, w / 2, net->layers[kNumLayers - 1].w, net->classes,
                               f.logits ? f.logits + i0 * px * net->classes : nullptr, f.measure, f.threshold, V.partial,
                               f.label ? f.label + i0 * px : nullptr, f.mask ? f.mask + i0 * px : nullptr,
@@ -732,6 +747,8 @@ hipError_t run_net(ssal_enet *net, const void *x, bool x_is_u8, int n, int h, in
                 const int ng = first[g + 1] - first[g];
                 if (li == 28)
                     HIP_RET(run_final(net, V[g], fin, first[g], ng, h, w, net->side[g]));
+                else if (li == 27 && fuse_5_1(net, fin))
+                    continue;
                 else
                     HIP_RET(run_layer_idx(net, li, (const char *)x + (size_t)first[g] * h * w * net->c_in * xelt, x_is_u8,
                                           V[g], ng, h, w, net->side[g]));
@@ -743,6 +760,8 @@ hipError_t run_net(ssal_enet *net, const void *x, bool x_is_u8, int n, int h, in
                 }
         } else if (li == 28) {
             HIP_RET(run_final(net, W, fin, 0, n, h, w, s));
+        } else if (li == 27 && fuse_5_1(net, fin)) {
+            continue;
         } else {
             HIP_RET(run_layer_idx(net, li, x, x_is_u8, W, n, h, w, s));
         }
@@ -1241,7 +1260,7 @@ SSAL_API int ssal_debug_get_knobs(char *json_out, int64_t cap)
     measure = 1;
     ablate = k.ablate;
 #endif
-    const int dflt = g_use_mfma && k.bnk_tw == 0 && k.bnk_xcd == 1 && k.img_groups == 2 && k.img_span == 4 && k.fuse_ends == 1 && ablate == 0 && !ssal::prof_enabled()
+    const int dflt = g_use_mfma && k.bnk_tw == 0 && k.bnk_xcd == 1 && k.img_groups == 2 && k.img_span == 4 && k.fuse_ends == 3 && ablate == 0 && !ssal::prof_enabled()
                      && ssal::g_trace_buf == nullptr;
     snprintf(json_out, (size_t)cap, "{\"kernel_family\": %d, \"bnk_tw\": %d, \"bnk_xcd\": %d, \"img_groups\": %d, \"img_span\": %d, \"fuse_ends\": %d, "
              "\"ablate\": %d, \"measure_build\": %d, \"profiling\": %d, \"defaults\": %d}", g_use_mfma ? 1 : 0,

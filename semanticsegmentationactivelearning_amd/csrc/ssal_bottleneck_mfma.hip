@@ -1009,14 +1009,14 @@ Knobs &knobs()
         q.bnk_xcd = 1;
         q.img_groups = 2;
         q.img_span = 4;
-        q.fuse_ends = 1;
+        q.fuse_ends = 3;
 #ifdef SSAL_MEASURE  // measurement builds only: the product library reads no environment
         auto env = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
         q.bnk_tw = env("SSAL_BNK_TW", 0);
         q.bnk_xcd = env("SSAL_BNK_XCD", 1);
         q.ablate = env("SSAL_ABLATE", 0);
         q.img_groups = env("SSAL_IMG_GROUPS", 2);
-        q.fuse_ends = env("SSAL_FUSE_ENDS", 1);
+        q.fuse_ends = env("SSAL_FUSE_ENDS", 3);
 #endif
         return q;
     }();

@@ -52,6 +52,11 @@ int final_score_blocks(int H, int W);
 hipError_t launch_final_score(const float *x, int N, int H, int W, const float *wF, int K,
                               float *logits, int measure, float threshold, double *partial,
                               uint8_t *label, uint8_t *mask, float *conf, hipStream_t s);
+// Bottleneck5_1 evaluated inside the Final + score kernel (score-only form; x5 = Bottleneck5_0's output [N,H,W,16])
+hipError_t launch_bnk4_final_score(const float *x5, int N, int H, int W, const float *wp, const float *ps, const float *pt,
+                                   const float *pa, const float *wc, const float *cs, const float *ct, const float *ca,
+                                   const float *we, const float *es, const float *et, const float *ra, const float *wF, int K,
+                                   int measure, double *partial, hipStream_t s);
 // scores[n] = sum(partial[n, 0..blocks)) / pixels, fixed summation order (bitwise reproducible)
 hipError_t launch_reduce_mean(const double *partial, int N, int blocks, double pixels,
                               double *scores, hipStream_t s);
@@ -113,7 +118,7 @@ hipError_t launch_upsample_mfma(const float *x, float *y, const uint8_t *code, i
 struct Knobs {
     int bnk_tw;      // 16 = force 8x16 tiles in the 128-channel bottleneck kernels
     int bnk_xcd;     // 1 = XCD-aware tile order in the 128-channel bottleneck kernels
-    int fuse_ends;   // bit 0: Initial + Bottleneck1_0 in one launch (default 1)
+    int fuse_ends;   // bit 0: Initial + Bottleneck1_0 in one launch; bit 1: Bottleneck5_1 inside Final + score (ranking pass); default 3
     int img_span;    // which layers run in image groups: 0 = Bottleneck2_1..3_8, 1 = + 2_0, 2 = 1_0..5_1, 3 = Initial..5_1, 4 = Initial..Final + score (default)
     int img_groups;  // ENet: the layers of img_span run as this many image groups on side streams (default 2; 1 = everything on the caller's stream)
 #ifdef SSAL_MEASURE

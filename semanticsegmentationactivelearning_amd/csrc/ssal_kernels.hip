@@ -400,45 +400,149 @@ struct FsTap {
 // the ds_read_b128 of 16 neighbouring pixels then fall on 16 different bank quads).
 constexpr int FS_T = 16, FS_TP = FS_T + 1, FS_PS = 20;
 
+// Bottleneck5_1 (width-4 regular bottleneck on 16 channels, enet_modules.py:526-599) evaluated inside the Final + score
+// kernel (F51 instantiations): the kernel's 17 x 17 input window is then COMPUTED from Bottleneck5_0's output instead of
+// loaded -- 5_1's 268 MB output (batch 8 x 1024 x 2048) is neither written nor read, and its launch (HBM-bound, its
+// width-4 GEMMs zero-padded to 16 MFMA columns) disappears.  272 MACs per pixel on wave-uniform (scalar-load) kernels:
+//   phase P  projection 16 -> 4 + BN + PReLU on the 19 x 19 window (exact zeros outside the image: SAME padding applies
+//            to the PROJECTED tensor) -> LDS
+//   phase C  3x3 conv 4 -> 4 + BN + PReLU, expansion 4 -> 16 + BN, + x, PReLU on the 17 x 17 window -> the LDS tile the
+//            transposed convolution reads (zeros outside the image, as the staged load writes them)
+// every chain in the order of k_bottleneck16 / the oracle ((kh, kw, ci) ascending fmaf, y = fmaf(acc, s, t)).
+struct Bnk4Args {
+    const float *x5;                 // Bottleneck5_0 output [N,H,W,16]
+    const float *wp, *ps, *pt, *pa;  // proj kernel [16][4], folded BN, alpha
+    const float *wc, *cs, *ct, *ca;  // conv kernel [3][3][4][4]
+    const float *we, *es, *et, *ra;  // exp kernel [4][16], folded BN [16], residual alpha [16]
+};
+constexpr int F51_PW = FS_TP + 2;    // projected window: 19 x 19
+
 // OUT = false: score only (the ranking pass): logits / label / mask / conf are not touched, which frees the
 // SGPRs their pointers would pin and lets the kernel taps stream two input channels at a time.
-template <int K, bool OUT>
+template <int K, bool OUT, bool F51 = false>
 __global__ __launch_bounds__(256) void k_final_score(const float *__restrict__ x, int N, int H,
                                                      int W, const float *__restrict__ wF,
                                                      float *__restrict__ logits, int measure,
                                                      float threshold, double *__restrict__ partial,
                                                      uint8_t *__restrict__ label,
                                                      uint8_t *__restrict__ mask,
-                                                     float *__restrict__ conf)
+                                                     float *__restrict__ conf, Bnk4Args b5)
 {
     __shared__ double red[4];
     __shared__ __attribute__((aligned(16))) float tile[FS_TP * FS_TP * FS_PS];
+    __shared__ __attribute__((aligned(16))) float p1[F51 ? F51_PW * F51_PW * 4 : 4];
     const int n = blockIdx.y;
     const long HW = (long)H * W;
     const int tiles_x = (W + FS_T - 1) / FS_T;
     const int i0 = (int)(blockIdx.x / tiles_x) * FS_T, j0 = (int)(blockIdx.x % tiles_x) * FS_T;
+    if (F51) {
+        const float *x5 = b5.x5 + (long)n * HW * 16;
+        // ---- phase P: both passes' loads are requested first (361 pixels over 256 threads)
+        float4 xin[2][4];
+        bool okp[2];
+#pragma unroll
+        for (int ps_ = 0; ps_ < 2; ++ps_) {
+            const int e = min((int)threadIdx.x + 256 * ps_, F51_PW * F51_PW - 1);
+            const int gi = i0 - 2 + e / F51_PW, gj = j0 - 2 + e % F51_PW;
+            okp[ps_] = gi >= 0 && gi < H && gj >= 0 && gj < W;
+            const float4 *xp = reinterpret_cast<const float4 *>(x5 + ((long)min(max(gi, 0), H - 1) * W + min(max(gj, 0), W - 1)) * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xin[ps_][q] = xp[q];
+        }
+#pragma unroll
+        for (int ps_ = 0; ps_ < 2; ++ps_) {
+            const int e = (int)threadIdx.x + 256 * ps_;
+            if (e < F51_PW * F51_PW) {  // wave-uniform except in the last active wave
+                const float xv[16] = {xin[ps_][0].x, xin[ps_][0].y, xin[ps_][0].z, xin[ps_][0].w, xin[ps_][1].x, xin[ps_][1].y,
+                                      xin[ps_][1].z, xin[ps_][1].w, xin[ps_][2].x, xin[ps_][2].y, xin[ps_][2].z, xin[ps_][2].w,
+                                      xin[ps_][3].x, xin[ps_][3].y, xin[ps_][3].z, xin[ps_][3].w};
+                float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int ci = 0; ci < 16; ++ci)
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) acc[f] = fmaf(xv[ci], b5.wp[ci * 4 + f], acc[f]);
+                float4 o;
+                o.x = okp[ps_] ? prelu_f(fmaf(acc[0], b5.ps[0], b5.pt[0]), b5.pa[0]) : 0.0f;
+                o.y = okp[ps_] ? prelu_f(fmaf(acc[1], b5.ps[1], b5.pt[1]), b5.pa[1]) : 0.0f;
+                o.z = okp[ps_] ? prelu_f(fmaf(acc[2], b5.ps[2], b5.pt[2]), b5.pa[2]) : 0.0f;
+                o.w = okp[ps_] ? prelu_f(fmaf(acc[3], b5.ps[3], b5.pt[3]), b5.pa[3]) : 0.0f;
+                reinterpret_cast<float4 *>(p1)[e] = o;
+            }
+        }
+        __syncthreads();
+        // ---- phase C: 289 pixels over 256 threads; the residual rows (L1 / L2 hits: phase P has just read them) first
+        float4 xr[2][4];
+        bool okc[2];
+#pragma unroll
+        for (int ps_ = 0; ps_ < 2; ++ps_) {
+            const int e = min((int)threadIdx.x + 256 * ps_, FS_TP * FS_TP - 1);
+            const int gi = i0 - 1 + e / FS_TP, gj = j0 - 1 + e % FS_TP;
+            okc[ps_] = gi >= 0 && gi < H && gj >= 0 && gj < W;
+            const float4 *xp = reinterpret_cast<const float4 *>(x5 + ((long)min(max(gi, 0), H - 1) * W + min(max(gj, 0), W - 1)) * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xr[ps_][q] = xp[q];
+        }
+#pragma unroll
+        for (int ps_ = 0; ps_ < 2; ++ps_) {
+            const int e = (int)threadIdx.x + 256 * ps_;
+            if (e < FS_TP * FS_TP) {
+                const int pi = e / FS_TP, pj = e % FS_TP;
+                float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const float4 pv = reinterpret_cast<const float4 *>(p1)[(pi + kh) * F51_PW + (pj + kw)];
+                        const float pc[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+                        for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+                            for (int f = 0; f < 4; ++f) acc[f] = fmaf(pc[ci], b5.wc[((kh * 3 + kw) * 4 + ci) * 4 + f], acc[f]);
+                    }
+                float qv[4];
+#pragma unroll
+                for (int f = 0; f < 4; ++f) qv[f] = prelu_f(fmaf(acc[f], b5.cs[f], b5.ct[f]), b5.ca[f]);
+                const float xres[16] = {xr[ps_][0].x, xr[ps_][0].y, xr[ps_][0].z, xr[ps_][0].w, xr[ps_][1].x, xr[ps_][1].y,
+                                        xr[ps_][1].z, xr[ps_][1].w, xr[ps_][2].x, xr[ps_][2].y, xr[ps_][2].z, xr[ps_][2].w,
+                                        xr[ps_][3].x, xr[ps_][3].y, xr[ps_][3].z, xr[ps_][3].w};
+                float out[16];
+#pragma unroll
+                for (int co = 0; co < 16; ++co) {
+                    float ev = 0.0f;
+#pragma unroll
+                    for (int ci = 0; ci < 4; ++ci) ev = fmaf(qv[ci], b5.we[ci * 16 + co], ev);
+                    const float v = prelu_f(fmaf(ev, b5.es[co], b5.et[co]) + xres[co], b5.ra[co]);
+                    out[co] = okc[ps_] ? v : 0.0f;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4 *>(tile + e * FS_PS + 4 * q) = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+            }
+        }
+    } else {
     // ---- stage the (16+1) x (16+1) pixel window (one halo row above, one halo column to the left) through LDS:
-    // every input pixel is fetched once per workgroup with coalesced float4 loads; outside the image = zeros
-    // (the transposed conv has no contribution from there).  All loads are issued before the first LDS write.
-    {
-        constexpr int NQ = FS_TP * FS_TP * 4, IT = (NQ + 255) / 256;  // float4 quads of the window
-        float4 st[IT];
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const int e = min((int)threadIdx.x + 256 * it, NQ - 1);
-            const int q = e & 3, pj = (e >> 2) % FS_TP, pi = (e >> 2) / FS_TP;
-            const int gi = i0 - 1 + pi, gj = j0 - 1 + pj;
-            const bool ok = gi >= 0 && gi < H && gj >= 0 && gj < W;
-            const long gp = (long)min(max(gi, 0), H - 1) * W + min(max(gj, 0), W - 1);
-            const float4 t = reinterpret_cast<const float4 *>(x + ((long)n * HW + gp) * 16)[q];
-            st[it] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+        // every input pixel is fetched once per workgroup with coalesced float4 loads; outside the image = zeros
+        // (the transposed conv has no contribution from there).  All loads are issued before the first LDS write.
+        {
+            constexpr int NQ = FS_TP * FS_TP * 4, IT = (NQ + 255) / 256;  // float4 quads of the window
+            float4 st[IT];
+    #pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int e = min((int)threadIdx.x + 256 * it, NQ - 1);
+                const int q = e & 3, pj = (e >> 2) % FS_TP, pi = (e >> 2) / FS_TP;
+                const int gi = i0 - 1 + pi, gj = j0 - 1 + pj;
+                const bool ok = gi >= 0 && gi < H && gj >= 0 && gj < W;
+                const long gp = (long)min(max(gi, 0), H - 1) * W + min(max(gj, 0), W - 1);
+                const float4 t = reinterpret_cast<const float4 *>(x + ((long)n * HW + gp) * 16)[q];
+                st[it] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+    #pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int e = (int)threadIdx.x + 256 * it;
+                if (e < NQ) *reinterpret_cast<float4 *>(tile + (e >> 2) * FS_PS + 4 * (e & 3)) = st[it];
+            }
         }
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const int e = (int)threadIdx.x + 256 * it;
-            if (e < NQ) *reinterpret_cast<float4 *>(tile + (e >> 2) * FS_PS + 4 * (e & 3)) = st[it];
-        }
-    }
+}
     __syncthreads();
     const int ti = threadIdx.x / FS_T, tj = threadIdx.x % FS_T;
     const int i = i0 + ti, j = j0 + tj;
@@ -512,11 +616,41 @@ __global__ __launch_bounds__(256) void k_final_score(const float *__restrict__ x
 
 int final_score_blocks(int H, int W) { return cdiv(H, FS_T) * cdiv(W, FS_T); }
 
+// Bottleneck5_1 + Final + score (score-only form): x5 = Bottleneck5_0's output
+hipError_t launch_bnk4_final_score(const float *x5, int N, int H, int W, const float *wp, const float *ps, const float *pt,
+                                   const float *pa, const float *wc, const float *cs, const float *ct, const float *ca,
+                                   const float *we, const float *es, const float *et, const float *ra, const float *wF, int K,
+                                   int measure, double *partial, hipStream_t s)
+{
+    dim3 grid(final_score_blocks(H, W), N), block(256);
+    const double pix = (double)N * H * W;
+    ProfScope prof("k_final_score<fused 5_1>", 2.0 * pix * 9 * 16 * K + 2.0 * pix * (16.0 * 4 + 9.0 * 4 * 4 + 4.0 * 16),
+                   4.0 * pix * 16, s);
+    Bnk4Args b = {x5, wp, ps, pt, pa, wc, cs, ct, ca, we, es, et, ra};
+#define SSAL_FS51(KK)                                                                                               \
+    case KK:                                                                                                        \
+        hipLaunchKernelGGL((k_final_score<KK, false, true>), grid, block, 0, s, nullptr, N, H, W, wF, nullptr, measure, \
+                           0.0f, partial, nullptr, nullptr, nullptr, b);                                            \
+        break;
+    switch (K) {
+        SSAL_FS51(2) SSAL_FS51(3) SSAL_FS51(4) SSAL_FS51(5) SSAL_FS51(6) SSAL_FS51(7) SSAL_FS51(8) SSAL_FS51(9)
+        SSAL_FS51(10) SSAL_FS51(11) SSAL_FS51(12) SSAL_FS51(13) SSAL_FS51(14) SSAL_FS51(15) SSAL_FS51(16)
+        SSAL_FS51(17) SSAL_FS51(18) SSAL_FS51(19) SSAL_FS51(20) SSAL_FS51(21) SSAL_FS51(22) SSAL_FS51(23)
+        SSAL_FS51(24) SSAL_FS51(25) SSAL_FS51(26) SSAL_FS51(27) SSAL_FS51(28) SSAL_FS51(29) SSAL_FS51(30)
+        SSAL_FS51(31) SSAL_FS51(32)
+    default:
+        return hipErrorInvalidValue;
+    }
+#undef SSAL_FS51
+    return hipGetLastError();
+}
+
 hipError_t launch_final_score(const float *x, int N, int H, int W, const float *wF, int K,
                               float *logits, int measure, float threshold, double *partial,
                               uint8_t *label, uint8_t *mask, float *conf, hipStream_t s)
 {
     dim3 grid(final_score_blocks(H, W), N), block(256);
+    const Bnk4Args b = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     ProfScope prof("k_final_score", 2.0 * (double)N * H * W * 9 * 16 * K,
                    4.0 * ((double)N * H * W * 16 + (logits ? (double)N * 4 * H * W * K : 0.0)) +
                        (double)N * 4 * H * W * ((label ? 1 : 0) + (mask ? 1 : 0) + (conf ? 4 : 0)), s);
@@ -525,10 +659,10 @@ hipError_t launch_final_score(const float *x, int N, int H, int W, const float *
     case KK:                                                                                               \
         if (out)                                                                                           \
             hipLaunchKernelGGL((k_final_score<KK, true>), grid, block, 0, s, x, N, H, W, wF, logits, measure, \
-                               threshold, partial, label, mask, conf);                                     \
+                               threshold, partial, label, mask, conf, b);                                  \
         else                                                                                               \
             hipLaunchKernelGGL((k_final_score<KK, false>), grid, block, 0, s, x, N, H, W, wF, logits, measure, \
-                               threshold, partial, label, mask, conf);                                     \
+                               threshold, partial, label, mask, conf, b);                                  \
         break;
     switch (K) {
         SSAL_FS(2) SSAL_FS(3) SSAL_FS(4) SSAL_FS(5) SSAL_FS(6) SSAL_FS(7) SSAL_FS(8) SSAL_FS(9)

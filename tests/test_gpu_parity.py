@@ -904,6 +904,35 @@ def test_spatial_dropout_op():
         xops.spatial_dropout(dev(x), 1.0)
 
 
+@pytest.mark.parametrize("classes,c_in,n,h,w", [(19, 3, 3, 8, 8), (19, 3, 2, 24, 40), (6, 4, 1, 136, 72), (2, 1, 5, 16, 8),
+                                                (32, 3, 2, 40, 24), (7, 3, 1, 264, 520)])
+def test_fused_ends_equal_the_per_layer_launches(classes, c_in, n, h, w):
+    """round 3: the ranking pass (score only) runs Initial + Bottleneck1_0 as one launch (k_initial_down16) and evaluates
+    Bottleneck5_1 inside the Final + score kernel; a score call that also returns labels takes the per-layer launches for
+    5_1 / Final, and `fuse_ends = 0` switches both fusions off.  Every combination must give the same bits, on tiles
+    that are cut by the image border on all four sides (odd tile counts, 1 / 3 / 4 input channels, 2 .. 32 classes)."""
+    from helpers import make_model
+    net, P = make_model(classes, c_in, seed=3)
+    x = syn.synth_frames_device(11, n, h, w, c_in)
+    want = None
+    try:
+        for fuse in (3, 1, 2, 0):
+            _lib.set_knob("fuse_ends", fuse)
+            for measure in ("entropy", "margin", "confidence"):
+                a = net.score(x, measure).cpu().numpy()
+                b, extra = net.score(x, measure, return_label=True)
+                assert np.array_equal(a, b.cpu().numpy()), (fuse, measure)
+                if fuse == 3 and measure == "entropy":
+                    want = {"label": extra["label"].cpu().numpy()}
+                want.setdefault(measure, a)
+                assert np.array_equal(a, want[measure]), "fuse_ends=%d changes the %s score" % (fuse, measure)
+                assert np.array_equal(extra["label"].cpu().numpy(), want["label"])
+    finally:
+        _lib.set_knob("fuse_ends", 3)
+    ref = orc.score_images(P, syn.synth_frames_f32(np.arange(11, 11 + n), h, w, c_in), "entropy")[0]
+    report_diff("fused ends vs oracle", want["entropy"], ref, exact=False, atol=1e-6)
+
+
 def test_image_group_streams_are_bit_identical(enet_c3k19):
     """the network runs as `img_groups` image chains on library-owned side streams (default: 2 chains over Initial .. Final +
     score): logits, labels and scores must not depend on the grouping (1 = caller's stream only, 2, 4; uneven groups for a
@@ -950,7 +979,7 @@ def test_repeated_calls_do_not_grow_device_memory(enet_c3k19):
 
 def test_knobs_are_reported_and_default():
     k = _lib.get_knobs()
-    assert k["defaults"] == 1 and k["measure_build"] == 0 and k["fuse_ends"] == 1 and k["ablate"] == 0 and "MEASUREMENT" not in k["version"]
+    assert k["defaults"] == 1 and k["measure_build"] == 0 and k["fuse_ends"] == 3 and k["ablate"] == 0 and "MEASUREMENT" not in k["version"]
     with pytest.raises(ValueError):
         _lib.set_knob("ablate", 1)  # no work-skipping switch in the product build
     _lib.set_knob("bnk_tw", 16)

@@ -737,35 +737,39 @@ hipError_t run_net(ssal_enet *net, const void *x, bool x_is_u8, int n, int h, in
             V[g].partial += i0 * final_score_blocks(h / 2, w / 2);
         }
     }
-    for (int li = 0; li < 29; ++li) {
-        if (G > 1 && li >= ga && li < gb) {
-            if (li == ga) {
-                HIP_RET(hipEventRecord(net->fork_ev, s));
-                for (int g = 0; g < G; ++g) HIP_RET(hipStreamWaitEvent(net->side[g], net->fork_ev, 0));
-            }
-            for (int g = 0; g < G; ++g) {  // layer-major issue order
-                const int ng = first[g + 1] - first[g];
-                if (li == 28)
-                    HIP_RET(run_final(net, V[g], fin, first[g], ng, h, w, net->side[g]));
-                else if (li == 27 && fuse_5_1(net, fin))
-                    continue;
-                else
-                    HIP_RET(run_layer_idx(net, li, (const char *)x + (size_t)first[g] * h * w * net->c_in * xelt, x_is_u8,
-                                          V[g], ng, h, w, net->side[g]));
-            }
-            if (li == gb - 1)
-                for (int g = 0; g < G; ++g) {
-                    HIP_RET(hipEventRecord(net->join_ev[g], net->side[g]));
-                    HIP_RET(hipStreamWaitEvent(s, net->join_ev[g], 0));
-                }
-        } else if (li == 28) {
-            HIP_RET(run_final(net, W, fin, 0, n, h, w, s));
-        } else if (li == 27 && fuse_5_1(net, fin)) {
-            continue;
-        } else {
-            HIP_RET(run_layer_idx(net, li, x, x_is_u8, W, n, h, w, s));
-        }
+    auto issue = [&](int li, int g) -> hipError_t {  // layer li of chain g (g < 0: the whole batch on the caller's stream)
+        const NetWorkspace &Vg = g < 0 ? W : V[g];
+        const int i0 = g < 0 ? 0 : first[g], ng = g < 0 ? n : first[g + 1] - first[g];
+        hipStream_t sg = g < 0 ? s : net->side[g];
+        if (li == 28) return run_final(net, Vg, fin, i0, ng, h, w, sg);
+        if (li == 27 && fuse_5_1(net, fin)) return hipSuccess;
+        return run_layer_idx(net, li, (const char *)x + (size_t)i0 * h * w * net->c_in * xelt, x_is_u8, Vg, ng, h, w, sg);
+    };
+    if (G == 1) {
+        for (int li = 0; li < 29; ++li) HIP_RET(issue(li, -1));
+        return hipSuccess;
     }
+    for (int li = 0; li < ga; ++li) HIP_RET(issue(li, -1));
+    HIP_RET(hipEventRecord(net->fork_ev, s));
+    for (int g = 0; g < G; ++g) HIP_RET(hipStreamWaitEvent(net->side[g], net->fork_ev, 0));
+    // layer-major issue order; with img_lag = L > 0 chain g runs L layers behind chain g - 1 (it starts when its
+    // predecessor has finished its first L layers): measured, see the table above
+    const int lag = kn.img_lag > 0 ? kn.img_lag : 0, nl = gb - ga;
+    for (int t = 0; t < nl + lag * (G - 1); ++t)
+        for (int g = 0; g < G; ++g) {
+            const int k = t - lag * g;
+            if (k < 0 || k >= nl) continue;
+            HIP_RET(issue(ga + k, g));
+            if (lag > 0 && k == lag - 1 && g + 1 < G) {
+                HIP_RET(hipEventRecord(net->join_ev[g], net->side[g]));
+                HIP_RET(hipStreamWaitEvent(net->side[g + 1], net->join_ev[g], 0));
+            }
+        }
+    for (int g = 0; g < G; ++g) {
+        HIP_RET(hipEventRecord(net->join_ev[g], net->side[g]));
+        HIP_RET(hipStreamWaitEvent(s, net->join_ev[g], 0));
+    }
+    for (int li = gb; li < 29; ++li) HIP_RET(issue(li, -1));
     return hipSuccess;
 }
 }  // namespace
@@ -1242,6 +1246,7 @@ SSAL_API int ssal_debug_set_knob(const char *name, int value)
     else if (n == "img_groups") k.img_groups = value;
     else if (n == "img_span") k.img_span = value;
     else if (n == "fuse_ends") k.fuse_ends = value;
+    else if (n == "img_lag") k.img_lag = value;
 #ifdef SSAL_MEASURE
     else if (n == "ablate") k.ablate = value;
 #endif
@@ -1260,7 +1265,7 @@ SSAL_API int ssal_debug_get_knobs(char *json_out, int64_t cap)
     measure = 1;
     ablate = k.ablate;
 #endif
-    const int dflt = g_use_mfma && k.bnk_tw == 0 && k.bnk_xcd == 1 && k.img_groups == 2 && k.img_span == 4 && k.fuse_ends == 3 && ablate == 0 && !ssal::prof_enabled()
+    const int dflt = g_use_mfma && k.bnk_tw == 0 && k.bnk_xcd == 1 && k.img_groups == 2 && k.img_span == 4 && k.fuse_ends == 3 && k.img_lag == 0 && ablate == 0 && !ssal::prof_enabled()
                      && ssal::g_trace_buf == nullptr;
     snprintf(json_out, (size_t)cap, "{\"kernel_family\": %d, \"bnk_tw\": %d, \"bnk_xcd\": %d, \"img_groups\": %d, \"img_span\": %d, \"fuse_ends\": %d, "
              "\"ablate\": %d, \"measure_build\": %d, \"profiling\": %d, \"defaults\": %d}", g_use_mfma ? 1 : 0,

@@ -18,6 +18,8 @@ def short(name):
     n = name.split("(")[0].replace("void ", "").replace("ssal::", "")
     if n.startswith("k_bottleneck16") or n.startswith("k_bottleneck_mfma"):
         return n.replace(" ", "")
+    if n.startswith("k_final_score"):  # k_final_score<19, false, true> = Bottleneck5_1 evaluated inside (bench: "k_final_score<fused 5_1>")
+        return "k_final_score<fused 5_1>" if n.replace(" ", "").endswith(",true>") else "k_final_score"
     if n.startswith("k_igemm"):
         return n.split(",")[0] + (",up2>" if "true" in n else ">")  # k_igemm<4, true> -> k_igemm<4,up2>;  <4, false> -> k_igemm<4>
     return n.split("<")[0]

@@ -1247,6 +1247,7 @@ SSAL_API int ssal_debug_set_knob(const char *name, int value)
     else if (n == "img_span") k.img_span = value;
     else if (n == "fuse_ends") k.fuse_ends = value;
     else if (n == "img_lag") k.img_lag = value;
+    else if (n == "ig_div") k.ig_div = value > 0 ? value : 0;
 #ifdef SSAL_MEASURE
     else if (n == "ablate") k.ablate = value;
 #endif
@@ -1265,7 +1266,7 @@ SSAL_API int ssal_debug_get_knobs(char *json_out, int64_t cap)
     measure = 1;
     ablate = k.ablate;
 #endif
-    const int dflt = g_use_mfma && k.bnk_tw == 0 && k.bnk_xcd == 1 && k.img_groups == 2 && k.img_span == 4 && k.fuse_ends == 3 && k.img_lag == 0 && ablate == 0 && !ssal::prof_enabled()
+    const int dflt = g_use_mfma && k.bnk_tw == 0 && k.bnk_xcd == 1 && k.img_groups == 2 && k.img_span == 4 && k.fuse_ends == 3 && k.img_lag == 0 && k.ig_div == 0 && ablate == 0 && !ssal::prof_enabled()
                      && ssal::g_trace_buf == nullptr;
     snprintf(json_out, (size_t)cap, "{\"kernel_family\": %d, \"bnk_tw\": %d, \"bnk_xcd\": %d, \"img_groups\": %d, \"img_span\": %d, \"fuse_ends\": %d, "
              "\"ablate\": %d, \"measure_build\": %d, \"profiling\": %d, \"defaults\": %d}", g_use_mfma ? 1 : 0,

@@ -46,6 +46,11 @@ hipError_t launch_conv_first(const void *x, bool x_is_u8, int N, int H, int W, i
 // tf.nn.max_pool(3x3, stride 2, SAME); C % 4 == 0
 hipError_t launch_maxpool3x3_s2(const float *x, int N, int H, int W, int C, float *y, hipStream_t s);
 
+// launches of one layer the caller runs side by side (image-group chains): the convolution launchers size their
+// "fill the chip" rules for 512 / concurrency workgroups per launch.  Thread-local.
+void set_launch_concurrency(int g);
+int launch_concurrency();
+
 // pyramid pooling (ICNET_SPEC conv5_3_pool* / conv5_3_sum): scratch = ppm_scratch_floats(N, H, C) floats
 int64_t ppm_scratch_floats(int N, int H, int C);
 hipError_t launch_ppm(const float *x, int N, int H, int W, int C, float *scratch, float *y, hipStream_t s);

@@ -370,7 +370,10 @@ int score_any(ssal_icnet *net, const void *x_dev, bool u8, int n, int h, int w, 
             HIP_TRY(hipStreamWaitEvent(q.s, net->fork_ev, 0));
         }
     }
-    HIP_TRY(run_trunk(net, grp, u8, h, w, true));
+    set_launch_concurrency(G);
+    const hipError_t trunk_rc = run_trunk(net, grp, u8, h, w, true);
+    set_launch_concurrency(1);
+    HIP_TRY(trunk_rc);
     for (int g = 0; g < G; ++g) {
         const Grp &q = grp[g];
         const int64_t i0 = first[g];

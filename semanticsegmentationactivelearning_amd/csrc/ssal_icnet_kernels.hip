@@ -656,7 +656,8 @@ hipError_t launch_igemm(const float *x, int N, int H, int W, int Cin, const floa
         q.tiles_x = cdiv_i(W, HT_W); q.tiles_y = cdiv_i(H, HT_H); q.tiles_n = a.CoutP / 32;
         const long ntiles = (long)N * q.tiles_x * q.tiles_y * q.tiles_n;
         // persistent workgroups: two per CU (67 KB of LDS each), a multiple of the column-tile count
-        long grid = 512 / q.tiles_n * q.tiles_n;
+        long grid = (512 / launch_concurrency()) / q.tiles_n * q.tiles_n;
+        if (grid < q.tiles_n) grid = q.tiles_n;
         if (grid > ntiles) grid = ntiles;
         if (ntiles < (1L << 31)) {
             ProfScope prof("k_conv3x3_c32", 2.0 * (double)a.M * 9 * Cin * Cout,
@@ -673,7 +674,7 @@ hipError_t launch_igemm(const float *x, int N, int H, int W, int Cin, const floa
     const int nb32 = a.CoutP / 32;
     // widest column tile that divides the padded channel count and still leaves >= 2 workgroups per CU
     int NT = nb32 % 4 == 0 ? 4 : (nb32 % 2 == 0 ? 2 : 1);
-    while (NT > 1 && (long)a.tiles_m * (nb32 / NT) < 512) NT >>= 1;
+    while (NT > 1 && (long)a.tiles_m * (nb32 / NT) < 512 / launch_concurrency()) NT >>= 1;
     a.tiles_n = nb32 / NT;
     a.ntiles = a.tiles_m * a.tiles_n;
     a.xcd_chunk = (a.ntiles + 7) / 8;
@@ -973,6 +974,13 @@ __global__ __launch_bounds__(256) void k_ppm_sum(const float4 *__restrict__ x, c
         y[o] = v;
     }
 }
+
+// how many launches of one layer the caller runs side by side (the image-group chains of the score path): the "fill the
+// chip" rules below -- the widest column tile that still leaves >= 512 workgroups, 512 persistent workgroups -- apply to
+// what is on the chip together, so each launch gets 512 / concurrency.  Thread-local: set around run_trunk by the caller.
+static thread_local int t_concurrency = 1;
+void set_launch_concurrency(int g) { t_concurrency = g < 1 ? 1 : g; }
+int launch_concurrency() { return knobs().ig_div > 0 ? knobs().ig_div : t_concurrency; }
 
 int64_t ppm_scratch_floats(int N, int H, int C) { return (int64_t)N * (PPM_SLOTS + (int64_t)PPM_CSLOTS * H) * C; }
 

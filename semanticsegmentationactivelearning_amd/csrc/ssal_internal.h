@@ -119,6 +119,7 @@ struct Knobs {
     int bnk_tw;      // 16 = force 8x16 tiles in the 128-channel bottleneck kernels
     int bnk_xcd;     // 1 = XCD-aware tile order in the 128-channel bottleneck kernels
     int fuse_ends;   // bit 0: Initial + Bottleneck1_0 in one launch; bit 1: Bottleneck5_1 inside Final + score (ranking pass); default 3
+    int ig_div;      // ICNet: the ">= 512 workgroups per launch" rules of k_igemm / k_conv3x3_c32 use 512 / ig_div; 0 (default) = the number of image-group chains of the call
     int img_lag;     // chain g of the image-group schedule starts this many layers behind chain g - 1 (default 0)
     int img_span;    // which layers run in image groups: 0 = Bottleneck2_1..3_8, 1 = + 2_0, 2 = 1_0..5_1, 3 = Initial..5_1, 4 = Initial..Final + score (default)
     int img_groups;  // ENet: the layers of img_span run as this many image groups on side streams (default 2; 1 = everything on the caller's stream)

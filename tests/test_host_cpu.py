@@ -339,3 +339,21 @@ def test_bench_scaling_default_and_common_step_count():
         for rank in range(world):
             mine = len(range(rank, bench.POOL, world))
             assert mine <= per <= steps * bs
+
+
+def test_bench_kernel_roofline_rows_and_committed_pmc():
+    """bench.kernel_roofline: bound from the arithmetic intensity against the fp32 ridge, achieved / frac per launch, PMC
+    traffic per launch from the newest committed pass (profiles/r03_pmc); packed-vector kernels are labelled as such"""
+    import bench
+    rnd, pmc = bench.load_pmc("enet")
+    assert rnd == "r03" and "k_bottleneck_mfma<32>" in pmc and "k_final_score<fused 5_1>" in pmc and "k_initial_down16" in pmc
+    d = {"launches": 30, "ms": 30 * 0.114, "flops": 30 * 9.127e9, "bytes": 30 * 268.5e6}
+    r = bench.kernel_roofline("k_bottleneck_mfma<32>", d, 3, pmc["k_bottleneck_mfma<32>"])
+    assert r["bound"] == "mfma" and r["pipe"] == "mfma" and r["launches_per_batch"] == 10 and abs(r["avg_us"] - 114.0) < 1e-6
+    assert abs(r["frac"] - 9.127e9 / 114e-6 / 157.3e12) < 1e-3 and 1.5 < r["traffic_over_algorithmic"] < 1.7
+    h = bench.kernel_roofline("k_bottleneck16<32,64,16>", {"launches": 6, "ms": 6 * 0.136, "flops": 6 * 9.13e9, "bytes": 6 * 537e6}, 1, None)
+    assert h["bound"] == "hbm" and h["unit"] == "GB/s" and h["traffic"] is None and abs(h["frac"] - 537e6 / 136e-6 / 8e12) < 1e-3
+    v = bench.kernel_roofline("k_final_score<fused 5_1>", {"launches": 1, "ms": 0.355, "flops": 23.9e9, "bytes": 268e6}, 1, None)
+    assert v["bound"] == "mfma" and v["pipe"].startswith("valu")
+    z = bench.kernel_roofline("k_reduce_mean", {"launches": 1, "ms": 0.003, "flops": 0.0, "bytes": 0.0}, 1, None)
+    assert z["bound"] == "latency" and z["frac"] is None

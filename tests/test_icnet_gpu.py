@@ -391,3 +391,54 @@ def test_image_group_streams_are_bit_identical(icnet19):
             assert all(np.array_equal(a, b) for a, b in zip(outs[0], ref)), "img_groups=%d changes the result" % g
     finally:
         _lib.set_knob("img_groups", 2)
+
+
+def test_interleaved_models_batches_and_shapes_match_the_single_stream_unfused_path(icnet19):
+    """soak: ENet (3- and 4-channel handles) and ICNet share ONE process-wide pool of side streams; 40 back-to-back calls
+    that interleave the models, the entry points (score / score with labels / forward), batch sizes 1..8 and frame sizes
+    must give exactly what the same sequence gives with everything on the caller's stream and every fusion off"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import make_model
+    from semanticsegmentationactivelearning_amd import _lib
+    icn, _ = icnet19
+    e3, _ = make_model(19, 3, seed=0)
+    e4, _ = make_model(6, 4, seed=1)
+    rng = np.random.default_rng(5)
+    plan = []
+    for _ in range(40):
+        kind = rng.choice(["e3", "e4", "icn", "e3_label", "e3_forward"])
+        n = int(rng.integers(1, 9))
+        h, w = [(64, 128), (32, 96), (96, 64), (128, 160)][int(rng.integers(0, 4))]
+        plan.append((kind, n, h, w, int(rng.integers(0, 2000)), ["entropy", "margin", "confidence"][int(rng.integers(0, 3))]))
+
+    def run():
+        out = []
+        for kind, n, h, w, first, measure in plan:
+            if kind == "icn":
+                out.append(icn.score(syn.synth_frames_device(first, n, h, w, 3), measure))
+            elif kind == "e4":
+                out.append(e4.score(syn.synth_frames_device(first, n, h, w, 4), measure))
+            elif kind == "e3_label":
+                s, e = e3.score(syn.synth_frames_device(first, n, h, w, 3), measure, return_label=True)
+                out += [s, e["label"]]
+            elif kind == "e3_forward":
+                out.append(e3(syn.synth_frames_device(first, n, h, w, 3), training=False)[:, ::7, ::5, :].clone())
+            else:
+                out.append(e3.score(syn.synth_frames_device(first, n, h, w, 3), measure))
+        torch.cuda.synchronize()
+        return [t.cpu().numpy() for t in out]
+
+    got = run()
+    again = run()
+    try:
+        _lib.set_knob("img_groups", 1)
+        _lib.set_knob("fuse_ends", 0)
+        want = run()
+    finally:
+        _lib.set_knob("img_groups", 2)
+        _lib.set_knob("fuse_ends", 3)
+    assert len(got) == len(want)
+    for i, (a, b, c) in enumerate(zip(got, want, again)):
+        assert np.array_equal(a, b), "call %d of the plan differs from the single-stream, unfused result" % i
+        assert np.array_equal(a, c), "call %d of the plan is not reproducible" % i

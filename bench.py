@@ -47,13 +47,19 @@ if ROOT not in sys.path:
 # the host driver of the GPU pool only supports dmabuf IPC: RCCL / device-tensor sharing across the ranks of one node
 # needs this before the HIP runtime comes up (it is exported on the pool already; kept here for any other launcher)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# streams -> hardware queues: the HIP runtime's default cap is 4 per process; the image-group schedule uses the caller's
+# stream + 2 side streams, an N > 1 rank adds RCCL's stream (and a prefetch stream in the real ranking loop).  Measured on
+# one GPU (profiles/r04_ab_hw_queues.txt): 4, 8 and 16 queues score the same, 2 (or an empty value) lose 11 %.
+if not os.environ.get("GPU_MAX_HW_QUEUES"):
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
 POOL = 2975          # Cityscapes train split size (BASELINE.json configs[1])
 TOP_K = 128          # BASELINE.json configs[2]
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector == fp32-input MFMA peak
 SCORE_TABLE = os.path.join(ROOT, "tests", "golden", "pool_scores.npz")
-PMC_ROUNDS = ("r03", "r02")  # newest committed PMC pass first
+PMC_ROUNDS = ("r04", "r03", "r02")  # newest committed PMC pass first
+DETAIL_FILE = os.path.join(ROOT, "gpurun_out", "bench_detail.json")
 ICNET_NOTE = ("ICNet as pinned by ICNET_SPEC.md -- the reference's models/icnet/icnet.py is an empty class: parity "
               "unpinned AND undefined")
 
@@ -128,6 +134,11 @@ def parse(argv=None):
     ap.add_argument("--knob", action="append", default=[], metavar="NAME=VALUE",
                     help="measurement runs only: ssal_debug_set_knob(NAME, VALUE) before anything is timed (needs "
                          "--allow-nondefault-knobs; the JSON line reports the knobs)")
+    ap.add_argument("--detail-file", default=DETAIL_FILE,
+                    help="full result (per-kernel flops / bytes / traffic, whole secondary legs); the stdout line carries "
+                         "the compact form and names this file")
+    ap.add_argument("--full-line", action="store_true",
+                    help="tools/*.sh: print the full result object on stdout instead of the compact line")
     ap.add_argument("--allow-digest-mismatch", action="store_true",
                     help="measurement builds whose results are invalid by construction (ablation): report, do not fail")
     return ap.parse_args(argv)
@@ -287,6 +298,73 @@ def roofline_leg(net, batch, measure, model, reps=3):
     roof["pass_floor_ms_per_batch"] = floor_ms
     roof["pass_frac_of_kernel_floors"] = floor_ms / (total_ms / reps) if total_ms > 0 else None
     return roof, rows
+
+
+# ---- the printed line ---------------------------------------------------------------------------------------
+LINE_LIMIT = 6000  # bytes: the driver keeps a bounded tail of stdout; round 3's 16 KB line lost secondary.c4 there
+
+
+def _r(v, nd=4):
+    return round(v, nd) if isinstance(v, float) else v
+
+
+def compact_rows(rows):
+    """roofline_all of the printed line: {kernel: {n = launches per batch, avg_us, frac, bound, traffic_over_algorithmic}}"""
+    return {k: {"n": v["launches_per_batch"], "avg_us": _r(v["avg_us"], 1), "frac": _r(v["frac"], 3), "bound": v["bound"],
+                "traffic_over_algorithmic": _r(v["traffic_over_algorithmic"], 2)} for k, v in rows.items()}
+
+
+def compact_roofline(roof):
+    """the contract's roofline object + what locates it (kernel, launch time, share); the rest lives in the detail file"""
+    keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "avg_launch_us",
+            "launches_per_batch", "share_of_gpu_time", "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch",
+            "pass_ms_per_batch", "pass_frac_of_kernel_floors")
+    return {k: _r(roof[k], 4) for k in keep if k in roof}
+
+
+def compact_line(full, detail_path):
+    """the ONE stdout line (<= LINE_LIMIT bytes): contract fields, compact roofline rows, short secondary legs; everything
+    else is in `detail_path` (full per-kernel figures, full secondary legs, per-kernel ms per batch)"""
+    line = {k: v for k, v in full.items() if k not in ("roofline", "roofline_all", "secondary", "cpu_baseline")}
+    if "roofline" in full:
+        line["roofline"] = compact_roofline(full["roofline"])
+    if "roofline_all" in full:
+        line["roofline_all"] = compact_rows(full["roofline_all"])
+    if "secondary" in full:
+        line["secondary"] = {}
+        for nm, sec in full["secondary"].items():
+            d = {"value": _r(sec["value"], 1), "unit": sec["unit"], "ms_per_step": _r(sec["ms_per_step"], 4),
+                 "steps": sec["steps"], "digest_match": sec["score_digest"]["match"], "config": sec["config"].split(";")[0][:80],
+                 "parity": "unpinned AND undefined (no reference ICNet exists: ICNET_SPEC.md)" if "undefined" in sec["config"]
+                           else "unpinned (no TensorFlow, no reference fixtures)"}
+            if "roofline" in sec:
+                d["dominant_kernel"] = sec["roofline"]["kernel"]
+                d["dominant_frac"] = _r(sec["roofline"]["frac"], 3)
+                d["dominant_avg_us"] = _r(sec["roofline"]["avg_launch_us"], 1)
+                d["pass_frac_of_kernel_floors"] = _r(sec["roofline"]["pass_frac_of_kernel_floors"], 3)
+            line["secondary"][nm] = d
+    if "cpu_baseline" in full:
+        line["cpu_baseline"] = full["cpu_baseline"]
+    line["detail_file"] = os.path.relpath(detail_path, ROOT) if detail_path else None
+    text = json.dumps(line)
+    if len(text) > LINE_LIMIT:  # never print a line the driver would cut: drop the widest optional parts first
+        for victim in ("roofline_all", "knobs"):
+            line.pop(victim, None)
+            text = json.dumps(line)
+            if len(text) <= LINE_LIMIT:
+                break
+    return text
+
+
+def write_detail(full, path):
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1, sort_keys=True)
+        return path
+    except OSError as e:  # a read-only checkout must not cost the bench line
+        log("detail file not written (%s)" % e)
+        return None
 
 
 # ---- one scoring leg ----------------------------------------------------------------------------------------
@@ -580,7 +658,8 @@ def main(argv=None):
         result["score_digest_verdict"] = ("MISMATCH: " + ", ".join(bad)) if bad else (
             "ok" if all(dg["match"] for _, dg in digests) else "ok (no committed table entry for: %s)"
             % ", ".join(nm for nm, dg in digests if dg["match"] is None))
-        print(json.dumps(result), flush=True)
+        detail = write_detail(result, args.detail_file)
+        print(json.dumps(result) if args.full_line else compact_line(result, detail), flush=True)
         if bad and not args.allow_digest_mismatch:
             log("score digest MISMATCH (%s): the timed kernels did not produce the committed scores" % ", ".join(bad))
             rc = 4

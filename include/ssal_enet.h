@@ -14,8 +14,14 @@
  *   - "dev" pointers are device (HBM) pointers owned by the caller and only borrowed for the call;
  *     "host" pointers are host memory.  The library owns only the weights inside a handle.
  *   - activations are fp32 NHWC, conv kernels HWIO, transposed-conv kernels HW-O-I (TF layouts);
- *     all launches are stream-ordered and asynchronous; a handle is re-entrant per stream as long
- *     as each concurrent call gets its own workspace.
+ *     all launches are stream-ordered and asynchronous.
+ *   - threading: forward / score / run_layer on a COMMITTED handle may be called from any number of host threads at
+ *     the same time, provided every concurrent call has its own stream and its own workspace (the image-group schedule
+ *     draws its fork / join events per call from a mutex-protected pool; its side streams are one process-wide pool per
+ *     device).  set_tensor / commit / destroy must not overlap any other call on the same handle.  A handle lives on
+ *     ONE device -- the device that was current at commit; a call made with another current device returns
+ *     SSAL_ESTATE (create one handle per device).  A call that fails half way still joins its side-stream chains into
+ *     the caller's stream before it returns.
  */
 #ifndef SSAL_ENET_H
 #define SSAL_ENET_H
@@ -194,7 +200,7 @@ int ssal_debug_probe(float *out_dev_256, void *stream);
  * whose ssal_version() says so. */
 int ssal_debug_set_knob(const char *name, int value);
 /* JSON object with the state of every switch that can change what a launch does or costs: kernel_family, bnk_tw,
- * bnk_xcd, img_groups, img_span, ablate, measure_build, profiling, defaults (1 iff all are at their shipping values).  bench.py prints it
+ * bnk_xcd, img_groups, img_span, fuse_ends, img_lag, ig_div, ablate, measure_build, profiling, defaults (1 iff all are at their shipping values).  bench.py prints it
  * in its result line and refuses to time anything else. */
 int ssal_debug_get_knobs(char *json_out, int64_t cap);
 

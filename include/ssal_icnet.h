@@ -7,7 +7,8 @@
  * operator uses the semantics the reference repository defines for it (SAME convolutions as
  * models/enet/enet_modules.py:205,538,565,581; batch-norm models/util/extra_ops.py:154-185; bilinear resize
  * inference.py:96-99; acquisition measures active_learning.py:239-263).  The entry points follow the pattern of
- * the ENet handle (include/ssal_enet.h): same conventions, status codes and ownership rules.
+ * the ENet handle (include/ssal_enet.h): same conventions, status codes, ownership and threading rules (concurrent
+ * forward / score calls on one committed handle need their own stream + workspace; one handle per device).
  */
 #ifndef SSAL_ICNET_H
 #define SSAL_ICNET_H
@@ -54,7 +55,9 @@ int ssal_icnet_score_nhwc_u8(ssal_icnet *net, const uint8_t *x_dev, int n, int h
 
 /* Named intermediate tensors of the LAST forward/score call on a workspace (every ICNET_SPEC layer output that is
  * materialised keeps its own buffer): byte offset into the workspace and NHWC dims.  SSAL_EINVAL for a name that
- * is not materialised (the 2x interpolations are evaluated inside the consuming convolution). */
+ * is not materialised (the 2x interpolations are evaluated inside the consuming convolution).  Every endpoint is valid
+ * after a FORWARD call; a SCORE call runs conv2_2 / conv2_3 as one fused launch each, so their *_1x1_reduce and *_3x3
+ * buffers keep whatever an earlier call left there (stale) -- inspect layer outputs after ssal_icnet_forward_nhwc. */
 int ssal_icnet_num_endpoints(const ssal_icnet *net);
 int ssal_icnet_endpoint_name(const ssal_icnet *net, int i, const char **name);
 int ssal_icnet_endpoint_info(const ssal_icnet *net, const char *name, int n, int h, int w, int64_t *offset,

@@ -195,6 +195,75 @@ def stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class DeviceState:
+    """Device-side state of one Python model object (mixin of models.ENet / models.ICNet).
+
+    * a C handle owns its weights on ONE device (``include/ssal_enet.h``): the model keeps one handle per device ordinal
+      and pushes the weights to a device the first time it is used there (and again after any variable changed);
+    * concurrent calls on one handle need their own workspace: workspaces are keyed by (device, current torch stream),
+      so two host threads scoring on two streams never share one (the header's re-entrancy contract).
+    ``_ws`` / ``_last_dims`` always describe the MOST RECENT call (endpoint views, ``pooling_argmax``).
+
+    The model provides ``_create_handle(L) -> c_void_p``, ``_push_tensors(L, handle)`` (set_tensor + commit),
+    ``_destroy_handle(L, handle)`` and ``variables``."""
+
+    def _init_device_state(self):
+        import threading
+        self._handles = {}        # device ordinal -> [handle, pushed_versions]
+        self._workspaces = {}     # (device ordinal, stream pointer) -> uint8 tensor
+        self._ws = None
+        self._last_dims = None
+        self._state_lock = threading.Lock()
+
+    @property
+    def _handle(self):
+        """the handle of the current device (None before the first call there)"""
+        torch = _torch()
+        ent = self._handles.get(torch.cuda.current_device()) if torch.cuda.is_available() else None
+        if ent is None and self._handles:
+            ent = next(iter(self._handles.values()))
+        return ent[0] if ent else None
+
+    def _sync_handle(self):
+        torch = _torch()
+        L = lib()
+        dev = torch.cuda.current_device()
+        with self._state_lock:  # two threads must not create / commit one handle at the same time
+            ent = self._handles.get(dev)
+            if ent is None:
+                ent = self._handles[dev] = [self._create_handle(L), None]
+            versions = tuple(v.version for v in self.variables)
+            if versions != ent[1]:
+                # commit rewrites the weight arena: no call may be in flight on this handle while it runs
+                torch.cuda.synchronize(dev)
+                self._push_tensors(L, ent[0])
+                ent[1] = versions
+            return ent[0]
+
+    def _workspace(self, nbytes, device):
+        torch = require_gpu()
+        key = (device.index if device.index is not None else torch.cuda.current_device(),
+               torch.cuda.current_stream(device).cuda_stream)
+        ws = self._workspaces.get(key)
+        if ws is None or ws.numel() < nbytes:
+            self._workspaces.pop(key, None)  # release before growing
+            if self._ws is ws:
+                self._ws = None
+            del ws
+            ws = self._workspaces[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        self._ws = ws
+        return ws
+
+    def _release_device_state(self):
+        try:
+            L = lib()
+            for ent in self._handles.values():
+                self._destroy_handle(L, ent[0])
+            self._handles = {}
+        except Exception:
+            pass
+
+
 def as_device_f32(x, device=None):
     """numpy / torch input -> contiguous float32 torch tensor on the current GPU."""
     torch = require_gpu()

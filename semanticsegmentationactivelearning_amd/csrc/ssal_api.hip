@@ -114,9 +114,7 @@ struct ssal_enet {
     float *arena = nullptr;
     size_t arena_floats = 0;
     bool committed = false;
-    // events of the image-group schedule (created on first use, run_net); the side streams are process-wide
-    hipStream_t side[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // borrowed, not owned
-    hipEvent_t fork_ev = nullptr, join_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int device = -1;  // the device the arena lives on (set by commit); calls on another device are refused
 };
 
 static void add_tensor(ssal_enet *h, const std::string &name, std::vector<int64_t> dims)
@@ -224,9 +222,6 @@ SSAL_API int ssal_enet_destroy(ssal_enet *net)
 {
     if (!net) return SSAL_OK;
     if (net->arena) (void)hipFree(net->arena);
-    for (int g = 0; g < 8; ++g)
-        if (net->join_ev[g]) (void)hipEventDestroy(net->join_ev[g]);
-    if (net->fork_ev) (void)hipEventDestroy(net->fork_ev);
     delete net;
     return SSAL_OK;
 }
@@ -402,13 +397,16 @@ SSAL_API int ssal_enet_commit(ssal_enet *net, void *stream)
     }
 
     hipStream_t st = (hipStream_t)stream;
-    if (net->arena && net->arena_floats < ab.host.size()) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (net->arena && (net->arena_floats < ab.host.size() || net->device != dev)) {  // a handle lives on ONE device
         HIP_TRY(hipFree(net->arena));
         net->arena = nullptr;
     }
     if (!net->arena) {
         HIP_TRY(hipMalloc((void **)&net->arena, ab.host.size() * sizeof(float)));
         net->arena_floats = ab.host.size();
+        net->device = dev;
     }
     HIP_TRY(hipMemcpyAsync(net->arena, ab.host.data(), ab.host.size() * sizeof(float),
                            hipMemcpyHostToDevice, st));
@@ -590,6 +588,7 @@ struct NetWorkspace {
     float *s1a, *s1b;      // [n,h/4,w/4,64]
     float *s2a, *s2b;      // [n,h/8,w/8,128]
     LayerTemps T;
+    int64_t t_img[3];      // floats of T.t0 / t1 / t2 per image (every temporary is sized in proportion to n)
     uint8_t *code1, *code2;
     double *partial;
     int64_t bytes;
@@ -620,6 +619,7 @@ NetWorkspace carve(const ssal_enet *net, void *ws, int64_t ws_bytes, int64_t n, 
     W.T.t1 = b.take<float>(mx[1]);
     W.T.t2 = b.take<float>(mx[2]);
     W.T.t3 = nullptr;
+    for (int k = 0; k < 3; ++k) W.t_img[k] = mx[k] / n;
     W.code1 = b.take<uint8_t>(n * (h / 4) * (w / 4) * 16);
     W.code2 = b.take<uint8_t>(n * (h / 8) * (w / 8) * 64);
     W.partial = b.take<double>(n * (int64_t)final_score_blocks((int)(h / 2), (int)(w / 2)));
@@ -632,6 +632,10 @@ int check_dims(const ssal_enet *net, int n, int h, int w)
 {
     if (!net) return fail(SSAL_EINVAL, "net is NULL");
     if (!net->committed) return fail(SSAL_ESTATE, "ssal_enet_commit() has not been called");
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != net->device)
+        return fail(SSAL_ESTATE, "the handle was committed on device %d but the current device is %d (one handle per device)",
+                    net->device, dev);
     if (n <= 0 || h <= 0 || w <= 0) return fail(SSAL_EINVAL, "bad dims n=%d h=%d w=%d", n, h, w);
     if (h % 8 || w % 8)
         return fail(SSAL_EINVAL, "ENet needs H and W divisible by 8 (got %dx%d)", h, w);
@@ -702,7 +706,7 @@ hipError_t run_final(const ssal_enet *net, const NetWorkspace &V, const FinalOut
 }
 
 // runs Initial .. Bottleneck5_1 and Final + score (per-block float64 partials in W.partial)
-hipError_t run_net(ssal_enet *net, const void *x, bool x_is_u8, int n, int h, int w, NetWorkspace &W,
+hipError_t run_net(const ssal_enet *net, const void *x, bool x_is_u8, int n, int h, int w, NetWorkspace &W,
                    const FinalOut &fin, hipStream_t s)
 {
     // image-group schedule: images are independent, so a span of layers runs as G chains of ~n / G images on G
@@ -723,24 +727,25 @@ hipError_t run_net(ssal_enet *net, const void *x, bool x_is_u8, int n, int h, in
     int first[9];  // group g = images [first[g], first[g + 1]): as even as n allows (a pool's last batch may be odd)
     for (int g = 0; g <= G; ++g) first[g] = (int)((long)g * n / G);
     const size_t xelt = x_is_u8 ? 1 : 4;
-    if (G > 1) {
-        if (!net->fork_ev) HIP_RET(hipEventCreateWithFlags(&net->fork_ev, hipEventDisableTiming));
-        for (int g = 0; g < G; ++g) {
-            if (!net->side[g]) HIP_RET(ssal::side_stream(g, &net->side[g]));
-            if (!net->join_ev[g]) HIP_RET(hipEventCreateWithFlags(&net->join_ev[g], hipEventDisableTiming));
-            const long i0 = first[g];
-            V[g] = W;
-            V[g].a0 += i0 * (h / 2) * (w / 2) * 16;  V[g].a1 += i0 * (h / 2) * (w / 2) * 16;
-            V[g].s1a += i0 * (h / 4) * (w / 4) * 64; V[g].s1b += i0 * (h / 4) * (w / 4) * 64;
-            V[g].s2a += i0 * (h / 8) * (w / 8) * 128; V[g].s2b += i0 * (h / 8) * (w / 8) * 128;
-            V[g].code1 += i0 * (h / 4) * (w / 4) * 16; V[g].code2 += i0 * (h / 8) * (w / 8) * 64;
-            V[g].partial += i0 * final_score_blocks(h / 2, w / 2);
-        }
+    for (int g = 0; g < G && G > 1; ++g) {
+        const long i0 = first[g];
+        V[g] = W;
+        V[g].a0 += i0 * (h / 2) * (w / 2) * 16;  V[g].a1 += i0 * (h / 2) * (w / 2) * 16;
+        V[g].s1a += i0 * (h / 4) * (w / 4) * 64; V[g].s1b += i0 * (h / 4) * (w / 4) * 64;
+        V[g].s2a += i0 * (h / 8) * (w / 8) * 128; V[g].s2b += i0 * (h / 8) * (w / 8) * 128;
+        // the temporaries of the generic (multi-launch) layer forms: a layer whose size guard sends it there must not
+        // share them with the other chains
+        V[g].T.t0 += i0 * W.t_img[0]; V[g].T.t1 += i0 * W.t_img[1]; V[g].T.t2 += i0 * W.t_img[2];
+        V[g].code1 += i0 * (h / 4) * (w / 4) * 16; V[g].code2 += i0 * (h / 8) * (w / 8) * 64;
+        V[g].partial += i0 * final_score_blocks(h / 2, w / 2);
     }
+    // fork / join events are private to this call (ssal::ChainSet): two host threads may score on one handle, each on
+    // its own stream and workspace
+    ssal::ChainSet cs;
     auto issue = [&](int li, int g) -> hipError_t {  // layer li of chain g (g < 0: the whole batch on the caller's stream)
         const NetWorkspace &Vg = g < 0 ? W : V[g];
         const int i0 = g < 0 ? 0 : first[g], ng = g < 0 ? n : first[g + 1] - first[g];
-        hipStream_t sg = g < 0 ? s : net->side[g];
+        hipStream_t sg = g < 0 ? s : cs.side[g];
         if (li == 28) return run_final(net, Vg, fin, i0, ng, h, w, sg);
         if (li == 27 && fuse_5_1(net, fin)) return hipSuccess;
         return run_layer_idx(net, li, (const char *)x + (size_t)i0 * h * w * net->c_in * xelt, x_is_u8, Vg, ng, h, w, sg);
@@ -750,25 +755,19 @@ hipError_t run_net(ssal_enet *net, const void *x, bool x_is_u8, int n, int h, in
         return hipSuccess;
     }
     for (int li = 0; li < ga; ++li) HIP_RET(issue(li, -1));
-    HIP_RET(hipEventRecord(net->fork_ev, s));
-    for (int g = 0; g < G; ++g) HIP_RET(hipStreamWaitEvent(net->side[g], net->fork_ev, 0));
+    HIP_RET(cs.begin(G, s));
     // layer-major issue order; with img_lag = L > 0 chain g runs L layers behind chain g - 1 (it starts when its
-    // predecessor has finished its first L layers): measured, see the table above
+    // predecessor has finished its first L layers): measured, see the table above.  An error inside the span still joins
+    // the chains (~ChainSet) before the call returns.
     const int lag = kn.img_lag > 0 ? kn.img_lag : 0, nl = gb - ga;
     for (int t = 0; t < nl + lag * (G - 1); ++t)
         for (int g = 0; g < G; ++g) {
             const int k = t - lag * g;
             if (k < 0 || k >= nl) continue;
             HIP_RET(issue(ga + k, g));
-            if (lag > 0 && k == lag - 1 && g + 1 < G) {
-                HIP_RET(hipEventRecord(net->join_ev[g], net->side[g]));
-                HIP_RET(hipStreamWaitEvent(net->side[g + 1], net->join_ev[g], 0));
-            }
+            if (lag > 0 && k == lag - 1 && g + 1 < G) HIP_RET(cs.link(g, g + 1));
         }
-    for (int g = 0; g < G; ++g) {
-        HIP_RET(hipEventRecord(net->join_ev[g], net->side[g]));
-        HIP_RET(hipStreamWaitEvent(s, net->join_ev[g], 0));
-    }
+    HIP_RET(cs.end());
     for (int li = gb; li < 29; ++li) HIP_RET(issue(li, -1));
     return hipSuccess;
 }
@@ -1183,6 +1182,7 @@ hipEvent_t get_event()
 }  // namespace
 
 bool prof_enabled() { return g_prof_on; }
+bool mfma_family() { return ::g_use_mfma; }
 
 void prof_begin(const char *kernel, double flops, double bytes, hipStream_t s)
 {
@@ -1198,18 +1198,100 @@ void prof_end(hipStream_t s)
 }  // namespace ssal
 
 namespace ssal {
+namespace {
+struct DevPool {
+    hipStream_t side[8] = {};
+    std::vector<hipEvent_t> events;
+};
+std::mutex g_pool_mu;
+std::map<int, DevPool> g_pools;  // keyed by device ordinal: a stream / event belongs to the device it was created on
+}  // namespace
+
 hipError_t side_stream(int g, hipStream_t *out)
 {
-    static hipStream_t pool[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    static std::mutex mu;
     if (g < 0 || g >= 8) return hipErrorInvalidValue;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!pool[g]) {
-        hipError_t e = hipStreamCreateWithFlags(&pool[g], hipStreamNonBlocking);
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    DevPool &p = g_pools[dev];
+    if (!p.side[g]) {
+        e = hipStreamCreateWithFlags(&p.side[g], hipStreamNonBlocking);
         if (e != hipSuccess) return e;
     }
-    *out = pool[g];
+    *out = p.side[g];
     return hipSuccess;
+}
+
+static hipError_t take_event(int dev, hipEvent_t *out)
+{
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        DevPool &p = g_pools[dev];
+        if (!p.events.empty()) {
+            *out = p.events.back();
+            p.events.pop_back();
+            return hipSuccess;
+        }
+    }
+    return hipEventCreateWithFlags(out, hipEventDisableTiming);
+}
+
+static void give_event(int dev, hipEvent_t ev)
+{
+    if (!ev) return;
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    g_pools[dev].events.push_back(ev);
+}
+
+hipError_t ChainSet::begin(int groups, hipStream_t s)
+{
+    if (groups < 1 || groups > 8 || open) return hipErrorInvalidValue;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    G = groups;
+    caller = s;
+    for (int g = 0; g < G && e == hipSuccess; ++g) e = side_stream(g, &side[g]);
+    if (e == hipSuccess) e = take_event(dev, &fork_ev);
+    for (int g = 0; g < G && e == hipSuccess; ++g) e = take_event(dev, &join_ev[g]);
+    if (e == hipSuccess) e = hipEventRecord(fork_ev, s);
+    for (int g = 0; g < G && e == hipSuccess; ++g) e = hipStreamWaitEvent(side[g], fork_ev, 0);
+    if (e != hipSuccess) {  // nothing has been launched on a side stream yet: hand the events back, no join needed
+        give_event(dev, fork_ev);
+        for (int g = 0; g < G; ++g) give_event(dev, join_ev[g]);
+        fork_ev = nullptr;
+        for (int g = 0; g < 8; ++g) join_ev[g] = nullptr;
+        return e;
+    }
+    open = true;
+    return hipSuccess;
+}
+
+hipError_t ChainSet::link(int g, int g2)
+{
+    if (!open || g < 0 || g >= G || g2 < 0 || g2 >= G) return hipErrorInvalidValue;
+    hipError_t e = hipEventRecord(join_ev[g], side[g]);
+    return e != hipSuccess ? e : hipStreamWaitEvent(side[g2], join_ev[g], 0);
+}
+
+hipError_t ChainSet::end()
+{
+    if (!open) return hipSuccess;
+    open = false;
+    int dev = 0;
+    hipError_t first = hipGetDevice(&dev);
+    for (int g = 0; g < G; ++g) {  // every chain is joined even if one of the calls fails
+        hipError_t e = hipEventRecord(join_ev[g], side[g]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(caller, join_ev[g], 0);
+        if (e != hipSuccess) {
+            (void)hipStreamSynchronize(side[g]);  // last resort: the chain must not outlive the call
+            if (first == hipSuccess) first = e;
+        }
+    }
+    give_event(dev, fork_ev);
+    for (int g = 0; g < G; ++g) give_event(dev, join_ev[g]);
+    return first;
 }
 }  // namespace ssal
 
@@ -1269,8 +1351,8 @@ SSAL_API int ssal_debug_get_knobs(char *json_out, int64_t cap)
     const int dflt = g_use_mfma && k.bnk_tw == 0 && k.bnk_xcd == 1 && k.img_groups == 2 && k.img_span == 4 && k.fuse_ends == 3 && k.img_lag == 0 && k.ig_div == 0 && ablate == 0 && !ssal::prof_enabled()
                      && ssal::g_trace_buf == nullptr;
     snprintf(json_out, (size_t)cap, "{\"kernel_family\": %d, \"bnk_tw\": %d, \"bnk_xcd\": %d, \"img_groups\": %d, \"img_span\": %d, \"fuse_ends\": %d, "
-             "\"ablate\": %d, \"measure_build\": %d, \"profiling\": %d, \"defaults\": %d}", g_use_mfma ? 1 : 0,
-             k.bnk_tw, k.bnk_xcd, k.img_groups, k.img_span, k.fuse_ends, ablate, measure, ssal::prof_enabled() ? 1 : 0, dflt);
+             "\"img_lag\": %d, \"ig_div\": %d, \"ablate\": %d, \"measure_build\": %d, \"profiling\": %d, \"defaults\": %d}", g_use_mfma ? 1 : 0,
+             k.bnk_tw, k.bnk_xcd, k.img_groups, k.img_span, k.fuse_ends, k.img_lag, k.ig_div, ablate, measure, ssal::prof_enabled() ? 1 : 0, dflt);
     return SSAL_OK;
 }
 

@@ -104,9 +104,7 @@ struct ssal_icnet {
     size_t arena_floats = 0;
     const float *zeros128 = nullptr;  // PReLU slopes of the fused bottleneck launches (slope 0 == ReLU)
     bool committed = false;
-    // events of the image-group schedule of the score path (created on first use); the side streams are process-wide
-    hipStream_t side[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t fork_ev = nullptr, join_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int device = -1;  // the device the arena lives on (set by commit); calls on another device are refused
 };
 
 namespace {
@@ -196,6 +194,10 @@ int check_dims(const ssal_icnet *net, int n, int h, int w)
 {
     if (!net) return fail(SSAL_EINVAL, "net is NULL");
     if (!net->committed) return fail(SSAL_ESTATE, "ssal_icnet_commit() has not been called");
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != net->device)
+        return fail(SSAL_ESTATE, "the handle was committed on device %d but the current device is %d (one handle per device)",
+                    net->device, dev);
     if (n <= 0 || h <= 0 || w <= 0) return fail(SSAL_EINVAL, "bad dims n=%d h=%d w=%d", n, h, w);
     if (h % 32 || w % 32) return fail(SSAL_EINVAL, "ICNet needs H and W divisible by 32 (got %dx%d)", h, w);
     // the convolution kernels address each tensor with 32-bit byte offsets; the largest one (conv1_sub1's output) holds
@@ -261,7 +263,7 @@ hipError_t run_trunk(const ssal_icnet *net, std::vector<Grp> &grp, bool x_is_u8,
             cw /= 2;
         }
         const int oh = ch / b.stride, ow = cw / b.stride;
-        if (fused && fused_bneck(b) && b.dil >= 1) {
+        if (fused && ssal::mfma_family() && fused_bneck(b) && b.dil >= 1) {
             // reduce -> 3x3 -> increase + identity shortcut -> ReLU == ENet's regular bottleneck with zero slopes: same
             // (kh, kw, ci)-ascending fmaf chains, same folded batch-norm, same `fmaf(e, s, t) + x` merge; a ReLU written as
             // PReLU(slope 0) yields -0.0 where max(v, 0) yields +0.0, which no later layer can tell apart (every consumer
@@ -343,16 +345,15 @@ int score_any(ssal_icnet *net, const void *x_dev, bool u8, int n, int h, int w, 
     // image-group schedule (same knob and same reasoning as ENet's run_net, ssal_api.hip): the batch runs as G chains of
     // ~n / G images on library-owned side streams, forked from / joined into the caller's stream with events
     int G = ssal::knobs().img_groups;
-    if (G < 2 || G > 8 || n < G || ssal::prof_enabled()) G = 1;
+    if (G < 2 || G > 8 || n < G || !ssal::mfma_family() || ssal::prof_enabled()) G = 1;
     const int64_t px = (int64_t)h * w, ppm_img = ppm_scratch_floats(1, h / 32, 1024);
     const int blocks = upscore_blocks(h / 4, w / 4);
     std::vector<Grp> grp(G);
     std::vector<int64_t> first(G + 1);
     for (int g = 0; g <= G; ++g) first[g] = (int64_t)g * n / G;
-    if (G > 1) {
-        if (!net->fork_ev) HIP_TRY(hipEventCreateWithFlags(&net->fork_ev, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(net->fork_ev, s));
-    }
+    // fork / join events are private to this call (ssal::ChainSet, ssal_api.hip); a failure half way still joins the chains
+    ssal::ChainSet cs;
+    if (G > 1) HIP_TRY(cs.begin(G, s));
     for (int g = 0; g < G; ++g) {
         const int64_t i0 = first[g];
         Grp &q = grp[g];
@@ -363,12 +364,7 @@ int score_any(ssal_icnet *net, const void *x_dev, bool u8, int n, int h, int w, 
         q.x = (const char *)x_dev + (size_t)i0 * px * net->c_in * (u8 ? 1 : 4);
         q.n = (int)(first[g + 1] - i0);
         q.s = s;
-        if (G > 1) {
-            if (!net->side[g]) HIP_TRY(ssal::side_stream(g, &net->side[g]));
-            if (!net->join_ev[g]) HIP_TRY(hipEventCreateWithFlags(&net->join_ev[g], hipEventDisableTiming));
-            q.s = net->side[g];
-            HIP_TRY(hipStreamWaitEvent(q.s, net->fork_ev, 0));
-        }
+        if (G > 1) q.s = cs.side[g];
     }
     set_launch_concurrency(G);
     const hipError_t trunk_rc = run_trunk(net, grp, u8, h, w, true);
@@ -380,11 +376,8 @@ int score_any(ssal_icnet *net, const void *x_dev, bool u8, int n, int h, int w, 
         HIP_TRY(launch_upscore(q.A("conv6_cls"), q.n, h / 4, w / 4, net->classes, measure, threshold, q.W.partial,
                                label_dev ? label_dev + i0 * px : nullptr, mask_dev ? mask_dev + i0 * px : nullptr,
                                conf_dev ? conf_dev + i0 * px : nullptr, q.s));
-        if (G > 1) {
-            HIP_TRY(hipEventRecord(net->join_ev[g], q.s));
-            HIP_TRY(hipStreamWaitEvent(s, net->join_ev[g], 0));
-        }
     }
+    HIP_TRY(cs.end());
     HIP_TRY(launch_reduce_mean(W.partial, n, upscore_blocks(h / 4, w / 4), (double)h * (double)w, scores_dev, s));
     return SSAL_OK;
 }
@@ -427,9 +420,6 @@ SSAL_API int ssal_icnet_destroy(ssal_icnet *net)
 {
     if (!net) return SSAL_OK;
     if (net->arena) (void)hipFree(net->arena);
-    for (int g = 0; g < 8; ++g)
-        if (net->join_ev[g]) (void)hipEventDestroy(net->join_ev[g]);
-    if (net->fork_ev) (void)hipEventDestroy(net->fork_ev);
     delete net;
     return SSAL_OK;
 }
@@ -497,13 +487,16 @@ SSAL_API int ssal_icnet_commit(ssal_icnet *net, void *stream)
         offs[sp.name] = o;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (net->arena && net->arena_floats < ab.host.size()) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (net->arena && (net->arena_floats < ab.host.size() || net->device != dev)) {  // a handle lives on ONE device
         HIP_TRY(hipFree(net->arena));
         net->arena = nullptr;
     }
     if (!net->arena) {
         HIP_TRY(hipMalloc((void **)&net->arena, ab.host.size() * sizeof(float)));
         net->arena_floats = ab.host.size();
+        net->device = dev;
     }
     HIP_TRY(hipMemcpyAsync(net->arena, ab.host.data(), ab.host.size() * sizeof(float), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));  // the staging vector dies at return

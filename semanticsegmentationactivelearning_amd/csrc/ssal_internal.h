@@ -128,10 +128,28 @@ struct Knobs {
 #endif
 };
 Knobs &knobs();
-// side stream g (0..7) of the image-group schedule: ONE process-wide pool shared by every handle (created on first use,
-// never destroyed).  Per-handle streams would exhaust the hardware queues of the process: with four or more user streams
-// alive two chains share a queue and the second model scored in a process ran 14 % slower.
-hipError_t side_stream(int g, hipStream_t *out);
+bool mfma_family();  // ssal_set_kernel_family: true = the MFMA-fused kernels (default), false = generic kernels everywhere
+// Image-group schedule plumbing shared by the ENet and ICNet handles.  Side streams: ONE pool per DEVICE, shared by every
+// handle of the process (created on first use, never destroyed) -- per-handle streams would exhaust the hardware queues of
+// the process (with more user streams than queues two chains share a queue and the second model scored in a process ran
+// 14 % slower).  Events: private to each CALL, drawn from a mutex-protected per-device pool and handed back once the join
+// has been enqueued (a wait that is already enqueued keeps the record it saw; re-recording the event later is harmless),
+// so any number of host threads may drive one handle on their own streams + workspaces.
+hipError_t side_stream(int g, hipStream_t *out);  // pool of the CURRENT device
+struct ChainSet {
+    int G = 0;
+    bool open = false;
+    hipStream_t caller = nullptr, side[8] = {};
+    hipEvent_t fork_ev = nullptr, join_ev[8] = {};
+    // records the fork point on `s` and makes the G side streams of the current device wait for it
+    hipError_t begin(int groups, hipStream_t s);
+    // chain g has reached a point chain g2 must wait for (img_lag experiments)
+    hipError_t link(int g, int g2);
+    // joins every chain into the caller's stream and returns the events; also the error path: a call that fails half way
+    // still joins, so that no chain keeps using the caller's workspace after the call has returned
+    hipError_t end();
+    ~ChainSet() { if (open) (void)end(); }
+};
 
 // phase-trace buffer the bottleneck launchers hand to their kernels (ssal_debug_set_trace; NULL = off)
 extern unsigned long long *g_trace_buf;

@@ -13,7 +13,7 @@ from ... import _lib
 from . import enet_modules as mod
 
 
-class ENet:
+class ENet(_lib.DeviceState):
     """https://arxiv.org/pdf/1606.02147.pdf"""
 
     def __init__(self, classes,
@@ -69,12 +69,9 @@ class ENet:
                                 "Bottleneck5_0", "Bottleneck5_1", "Final"])
         for nm in self._layer_names:
             getattr(self, nm)._owner = self
-        self._handle = None
         self._c_in = None
-        self._pushed_versions = None
-        self._ws = None
+        self._init_device_state()  # per-device handles, per-(device, stream) workspaces (_lib.DeviceState)
         self._endpoints = []
-        self._last_dims = None
         self.outputs = []
 
     # ---- keras-like surface ----------------------------------------------------------------
@@ -127,40 +124,25 @@ class ENet:
         return list(self._endpoints)
 
     # ---- device handle ---------------------------------------------------------------------
-    def _versions(self):
-        return tuple(v.version for v in self.variables)
+    def _create_handle(self, L):
+        h = ctypes.c_void_p()
+        _lib.check(L.ssal_enet_create(self._c_in, self.classes, ctypes.byref(h)))
+        return h
 
-    def _sync_handle(self):
-        L = _lib.lib()
-        if self._handle is None:
-            h = ctypes.c_void_p()
-            _lib.check(L.ssal_enet_create(self._c_in, self.classes, ctypes.byref(h)))
-            self._handle = h
-        versions = self._versions()
-        if versions != self._pushed_versions:
-            for nm in self._layer_names:
-                for attr, var in getattr(self, nm).abi_tensors().items():
-                    arr = var.numpy()
-                    _lib.check(L.ssal_enet_set_tensor(
-                        self._handle, ("%s.%s" % (nm, attr)).encode(),
-                        arr.ctypes.data_as(ctypes.c_void_p), arr.size))
-            _lib.check(L.ssal_enet_commit(self._handle, _lib.stream_ptr()))
-            self._pushed_versions = versions
-        return self._handle
+    def _push_tensors(self, L, handle):
+        for nm in self._layer_names:
+            for attr, var in getattr(self, nm).abi_tensors().items():
+                arr = var.numpy()
+                _lib.check(L.ssal_enet_set_tensor(
+                    handle, ("%s.%s" % (nm, attr)).encode(),
+                    arr.ctypes.data_as(ctypes.c_void_p), arr.size))
+        _lib.check(L.ssal_enet_commit(handle, _lib.stream_ptr()))
+
+    def _destroy_handle(self, L, handle):
+        L.ssal_enet_destroy(handle)
 
     def __del__(self):
-        try:
-            if self._handle is not None:
-                _lib.lib().ssal_enet_destroy(self._handle)
-                self._handle = None
-        except Exception:
-            pass
-
-    def _workspace(self, nbytes, device):
-        torch = _lib.require_gpu()
-        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
-            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        return self._ws
+        self._release_device_state()
 
     def _prepare(self, inputs, training):
         if training:

@@ -93,7 +93,7 @@ def conv_layers(c_in, classes, kernel_initializer=None):
     return L
 
 
-class ICNet:
+class ICNet(_lib.DeviceState):
     """
     http://openaccess.thecvf.com/content_ECCV_2018/papers/Hengshuang_Zhao_ICNet_for_Real-Time_ECCV_2018_paper.pdf
     (the paper the reference's empty ``models/icnet/icnet.py:3`` cites; architecture pinned in ICNET_SPEC.md)
@@ -105,11 +105,8 @@ class ICNet:
         self.kernel_initializer = kernel_initializer
         self.built = False
         self._layers = []
-        self._handle = None
         self._c_in = None
-        self._pushed_versions = None
-        self._ws = None
-        self._last_dims = None
+        self._init_device_state()  # per-device handles, per-(device, stream) workspaces (_lib.DeviceState)
         self.outputs = []
 
     # ---- keras-like surface ----------------------------------------------------------------
@@ -151,37 +148,24 @@ class ICNet:
         return len(seen)
 
     # ---- device handle ---------------------------------------------------------------------
-    def _sync_handle(self):
-        L = _lib.lib()
-        if self._handle is None:
-            h = ctypes.c_void_p()
-            _lib.check(L.ssal_icnet_create(self._c_in, self.classes, ctypes.byref(h)))
-            self._handle = h
-        versions = tuple(v.version for v in self.variables)
-        if versions != self._pushed_versions:
-            for layer in self._layers:
-                for attr, var in layer.abi_tensors().items():
-                    arr = var.numpy()
-                    _lib.check(L.ssal_icnet_set_tensor(self._handle, ("%s.%s" % (layer.name, attr)).encode(),
-                                                       arr.ctypes.data_as(ctypes.c_void_p), arr.size))
-            _lib.check(L.ssal_icnet_commit(self._handle, _lib.stream_ptr()))
-            self._pushed_versions = versions
-        return self._handle
+    def _create_handle(self, L):
+        h = ctypes.c_void_p()
+        _lib.check(L.ssal_icnet_create(self._c_in, self.classes, ctypes.byref(h)))
+        return h
+
+    def _push_tensors(self, L, handle):
+        for layer in self._layers:
+            for attr, var in layer.abi_tensors().items():
+                arr = var.numpy()
+                _lib.check(L.ssal_icnet_set_tensor(handle, ("%s.%s" % (layer.name, attr)).encode(),
+                                                   arr.ctypes.data_as(ctypes.c_void_p), arr.size))
+        _lib.check(L.ssal_icnet_commit(handle, _lib.stream_ptr()))
+
+    def _destroy_handle(self, L, handle):
+        L.ssal_icnet_destroy(handle)
 
     def __del__(self):
-        try:
-            if self._handle is not None:
-                _lib.lib().ssal_icnet_destroy(self._handle)
-                self._handle = None
-        except Exception:
-            pass
-
-    def _workspace(self, nbytes, device):
-        torch = _lib.require_gpu()
-        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
-            self._ws = None  # release before growing
-            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        return self._ws
+        self._release_device_state()
 
     def _prepare(self, inputs, training):
         if training:

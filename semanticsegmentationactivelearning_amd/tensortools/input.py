@@ -68,6 +68,12 @@ class _Dataset:
 _PINNED_SLOTS = {}
 
 
+def _drop_slots(bases):
+    """finalizer of an InputStage: its ring slots leave the table with it"""
+    for base in list(bases):
+        _PINNED_SLOTS.pop(base, None)
+
+
 def copy_issued(tensor, event):
     """Tell the InputStage that owns the page-locked memory behind ``tensor`` (a batch it yielded, or any slice / view /
     re-wrapped copy-free alias of one) that an asynchronous host-to-device copy reading it has been issued and is
@@ -81,9 +87,9 @@ def copy_issued(tensor, event):
     for base, (nbytes, stage_ref, slot) in list(_PINNED_SLOTS.items()):
         if base <= ptr < base + nbytes:
             stage = stage_ref()
-            if stage is None:
+            if stage is None:  # a dead stage's stale range: drop it and keep looking (a live stage may own this memory now)
                 _PINNED_SLOTS.pop(base, None)
-                return False
+                continue
             stage._pin_events.setdefault(slot, []).append(event)
             return True
     return False
@@ -113,6 +119,8 @@ class InputStage:
         self._pinned = []  # ring of page-locked image batch buffers (allocated lazily, reused)
         self._pin_pos = 0
         self._pin_events = {}  # slot -> event of the async host-to-device copy still reading that slot
+        self._slot_bases = set()  # this stage's keys in _PINNED_SLOTS; removed when the stage dies
+        weakref.finalize(self, _drop_slots, self._slot_bases)
         if len(input_shape) == 3:
             self.shape = list(input_shape)
         elif len(input_shape) == 2:
@@ -226,9 +234,11 @@ class InputStage:
         if self._pinned[slot] is None or self._pinned[slot].numel() < need or self._pinned[slot].dtype != dtype:
             if self._pinned[slot] is not None:
                 _PINNED_SLOTS.pop(self._pinned[slot].data_ptr(), None)
+                self._slot_bases.discard(self._pinned[slot].data_ptr())
             self._pinned[slot] = torch.empty(need, dtype=dtype, pin_memory=True)
             buf = self._pinned[slot]
             _PINNED_SLOTS[buf.data_ptr()] = (buf.numel() * buf.element_size(), weakref.ref(self), slot)
+            self._slot_bases.add(buf.data_ptr())
         out = self._pinned[slot][:need].view(shape)
         np.stack(images, out=out.numpy())
         return out

@@ -150,3 +150,60 @@ def test_shard_longer_than_agreed_length_fails_on_every_rank_after_the_collectiv
         calls, verdict = open(tmp_path / ("verdict_%d.txt" % r)).read().split("|", 1)
         assert calls == "['all_gather_into_tensor']", calls
         assert verdict.startswith("ValueError") and "[1]" in verdict, verdict
+
+
+def _c3_worker(rank, world, port, num, k, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    from semanticsegmentationactivelearning_amd import active_learning as al
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        scores = _fake_scores(num)
+        pos = al.shard_positions(num, rank, world)
+        assert len(pos) == 372 and int((pos < 0).sum()) == (0 if rank < num % world else 1)  # 2975 = 8 * 371 + 7
+        mine = pos[pos >= 0]
+        # the bench's strong-scaling pass: every rank runs the SAME 47 steps of 8 (a short shard's last batch wraps onto
+        # batch 0: duplicates carry the same bits); then pads locally to 47 * 8 = 376 entries and all-gathers once
+        per_rank = (num + world - 1) // world
+        steps = (per_rank + 7) // 8
+        assert (per_rank, steps) == (372, 47)
+        batches = [mine[b * 8:(b + 1) * 8] for b in range((len(mine) + 7) // 8)]
+        order = np.concatenate([batches[s % len(batches)] for s in range(steps)])
+        idx, sc = al.pad_to_length(torch.from_numpy(order), torch.from_numpy(scores[order]), steps * 8)
+        with _CollectiveCounter() as cc:
+            all_idx, all_sc = al.all_gather_scores(idx, sc)
+        assert cc.calls == ["all_gather_into_tensor"], cc.calls
+        assert tuple(all_idx.shape) == (world * steps * 8,)
+        low, uc = al.finish_ranking(all_idx.numpy(), all_sc.numpy(), num, np.arange(num), k)
+        # and the library's own one-call form on the un-wrapped shard: exactly one collective as well
+        with _CollectiveCounter() as cc2:
+            low2, uc2 = al.merge_and_rank(torch.from_numpy(mine), torch.from_numpy(scores[mine]), num, np.arange(num), k)
+        assert cc2.calls == ["all_gather_into_tensor"], cc2.calls
+        assert set(low.tolist()) == set(low2.tolist()) and (uc == uc2).all()
+        np.save(os.path.join(out_dir, "low_%d.npy" % rank), np.sort(low))
+        np.save(os.path.join(out_dir, "uc_%d.npy" % rank), uc)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_8_exact_c3_split_one_collective_top_128(tmp_path):
+    """BASELINE configs[2] rehearsed on CPU (gloo, world_size = 8): 2975 examples -> 372 per rank (ranks 0..6 hold 372
+    examples, rank 7 holds 371 + one sentinel), k = 128, `strong_steps` = 47 on every rank, ONE all-gather, identical
+    selection on all 8 ranks and equal to the single-process / reference argpartition result"""
+    import bench
+    from semanticsegmentationactivelearning_amd import active_learning as al
+    num, k, world = bench.POOL, bench.TOP_K, 8
+    assert (num, k) == (2975, 128)
+    port = _free_port()
+    mp.spawn(_c3_worker, args=(world, port, num, k, str(tmp_path)), nprocs=world, join=True)
+    lows = [np.load(tmp_path / ("low_%d.npy" % r)) for r in range(world)]
+    ucs = [np.load(tmp_path / ("uc_%d.npy" % r)) for r in range(world)]
+    for r in range(1, world):
+        assert (lows[r] == lows[0]).all() and (ucs[r] == ucs[0]).all()
+    scores = _fake_scores(num)
+    ref = np.argpartition(scores.astype(np.float32), k)[:k]
+    assert set(ref.tolist()) == set(lows[0].tolist()) and len(lows[0]) == k
+    want_low, want_uc = al.finish_ranking(np.arange(num), scores, num, np.arange(num), k)
+    assert (np.sort(want_low) == lows[0]).all() and (want_uc == ucs[0]).all()

@@ -527,6 +527,9 @@ def test_full_resolution_image_bit_exact(enet_c3k19):
     # the frame just checked against the oracle is entry 100 of the table bench.py's score_digest is compared with
     table = pool_score_table("enet", 3, 19, 1024, 2048, "entropy", 0)
     assert scores.cpu().numpy()[0] == table[100], "HIP score of frame 100 != committed pool_scores.npz entry"
+    # ... and the SHIPPING ranking-pass form (no outputs: Initial + 1_0 in one launch, 5_1 inside Final + score) of the same
+    # frame gives the same bits as the unfused tail that was just compared with the oracle
+    assert net.score(xd, "entropy").cpu().numpy()[0] == table[100], "fused-ends score of frame 100 != oracle-checked score"
 
 
 def test_full_resolution_c5_rgb_nir_frame_bit_exact(enet_c4k6):
@@ -546,6 +549,7 @@ def test_full_resolution_c5_rgb_nir_frame_bit_exact(enet_c4k6):
     report_diff("C5 1024x2048x4 mean", scores.cpu().numpy(), want_mean, exact=False, atol=1e-6)
     table = pool_score_table("enet", 4, 6, 1024, 2048, "entropy", 1)
     assert scores.cpu().numpy()[0] == table[100], "HIP score of C5 frame 100 != committed pool_scores.npz entry"
+    assert net.score(xd, "entropy").cpu().numpy()[0] == table[100], "fused-ends score of C5 frame 100 != oracle-checked score"
 
 
 def test_pool_score_table_entries_reproduce_in_other_batch_compositions(enet_c3k19):
@@ -959,6 +963,65 @@ def test_image_group_streams_are_bit_identical(enet_c3k19):
         _lib.set_knob("img_groups", 2)
         _lib.set_knob("img_span", 4)
     assert _lib.get_knobs()["defaults"] == 1
+
+
+def test_two_host_threads_share_one_handle(enet_c3k19):
+    """include/ssal_enet.h: a handle is re-entrant -- any number of host threads may score on it, each on its own stream and
+    workspace.  Two threads x two torch streams x one model object, interleaved for many calls, each preceded by work on
+    its own stream that the chains must wait for (the input is produced on that stream right before the call): every
+    score must equal the single-threaded result bit for bit (fork / join events are per call, ssal::ChainSet)."""
+    import threading
+    net, _ = enet_c3k19
+    h, w = 256, 512
+    firsts = [(3, 4), (200, 3)]
+    want = [net.score(syn.synth_frames_device(f, n, h, w, 3), "entropy").cpu().numpy() for f, n in firsts]
+    torch.cuda.synchronize()
+    errors, results = [], [[], []]
+    start = threading.Barrier(2)
+
+    def worker(t):
+        try:
+            f, n = firsts[t]
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                start.wait()
+                for it in range(24):
+                    x = torch.empty((n, h, w, 3), dtype=torch.float32, device="cuda")
+                    x.fill_(float("nan"))                              # a chain that starts early scores NaNs
+                    syn.synth_frames_device(f, n, h, w, 3, out=x)      # producer on THIS thread's stream
+                    results[t].append(net.score(x, "entropy"))
+                stream.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for t in range(2):
+        assert len(results[t]) == 24
+        for r in results[t]:
+            assert np.array_equal(r.cpu().numpy(), want[t]), (t, r.cpu().numpy(), want[t])
+    assert len(net._workspaces) >= 3  # main stream + one workspace per worker stream
+
+
+def test_failed_call_leaves_no_chain_running(enet_c3k19):
+    """a call that is refused (workspace too small) returns its status and the handle keeps working; nothing of the refused
+    call is left on the side streams"""
+    import ctypes
+    net, _ = enet_c3k19
+    x = syn.synth_frames_device(7, 2, 64, 128, 3)
+    want = net.score(x, "entropy").cpu().numpy()
+    L = _lib.lib()
+    scores = torch.empty((2,), dtype=torch.float64, device="cuda")
+    small = torch.empty((4096,), dtype=torch.uint8, device="cuda")
+    rc = L.ssal_enet_score_nhwc(net._handle, _lib.dev_ptr(x), 2, 64, 128, 0, 0.0, _lib.dev_ptr(scores, torch.float64, "scores"),
+                                None, None, None, _lib.dev_ptr(small), small.numel(), _lib.stream_ptr())
+    assert rc == 5  # SSAL_ENOMEM
+    assert np.array_equal(net.score(x, "entropy").cpu().numpy(), want)
 
 
 def test_repeated_calls_do_not_grow_device_memory(enet_c3k19):

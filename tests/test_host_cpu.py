@@ -357,3 +357,25 @@ def test_bench_kernel_roofline_rows_and_committed_pmc():
     assert v["bound"] == "mfma" and v["pipe"].startswith("valu")
     z = bench.kernel_roofline("k_reduce_mean", {"launches": 1, "ms": 0.003, "flops": 0.0, "bytes": 0.0}, 1, None)
     assert z["bound"] == "latency" and z["frac"] is None
+
+
+def test_bench_line_is_compact_and_keeps_every_leg():
+    """the driver keeps a bounded tail of stdout: the printed line must stay under bench.LINE_LIMIT bytes and still carry
+    the contract fields, the dominant kernel's roofline, one compact row per kernel and BOTH secondary legs (round 3's
+    16 KB line lost secondary.c4); the full figures go to the detail file the line names"""
+    import json
+    import bench
+    full = json.load(open(os.path.join(os.path.dirname(bench.__file__), "profiles", "r03_bench_enet_full_pool.json")))
+    assert len(json.dumps(full)) > 15000  # the round-3 line, as the driver received it
+    text = bench.compact_line(full, os.path.join(bench.ROOT, "gpurun_out", "bench_detail.json"))
+    assert len(text) <= bench.LINE_LIMIT
+    line = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "score_digest"):
+        assert k in line, k
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us"):
+        assert k in line["roofline"], k
+    assert line["secondary"]["c4"]["value"] > 0 and line["secondary"]["c5"]["value"] > 0
+    assert "undefined" in line["secondary"]["c4"]["parity"]
+    assert set(line["roofline_all"]) == set(full["roofline_all"])
+    assert line["detail_file"] == os.path.join("gpurun_out", "bench_detail.json")

@@ -393,6 +393,52 @@ def test_image_group_streams_are_bit_identical(icnet19):
         _lib.set_knob("img_groups", 2)
 
 
+def test_two_host_threads_share_one_handle_and_family_switch(icnet19):
+    """include/ssal_icnet.h: a handle is re-entrant per (stream, workspace).  Two host threads x two torch streams on ONE
+    ICNet model, inputs produced on the thread's own stream right before each call; then ssal_set_kernel_family(0) -- the
+    per-layer launches on the caller's stream only -- gives the same bits (the switch reaches ICNet's fused blocks)"""
+    import threading
+    net, _ = icnet19
+    h, w = 128, 256
+    firsts = [(11, 4), (300, 3)]
+    want = [net.score(syn.synth_frames_device(f, n, h, w, 3), "margin").cpu().numpy() for f, n in firsts]
+    torch.cuda.synchronize()
+    errors, results = [], [[], []]
+    start = threading.Barrier(2)
+
+    def worker(t):
+        try:
+            f, n = firsts[t]
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                start.wait()
+                for it in range(12):
+                    x = torch.empty((n, h, w, 3), dtype=torch.float32, device="cuda")
+                    x.fill_(float("nan"))
+                    syn.synth_frames_device(f, n, h, w, 3, out=x)
+                    results[t].append(net.score(x, "margin"))
+                stream.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for t in range(2):
+        for r in results[t]:
+            assert np.array_equal(r.cpu().numpy(), want[t]), (t, r.cpu().numpy(), want[t])
+    try:
+        _lib.lib().ssal_set_kernel_family(0)
+        for (f, n), wnt in zip(firsts, want):
+            assert np.array_equal(net.score(syn.synth_frames_device(f, n, h, w, 3), "margin").cpu().numpy(), wnt)
+    finally:
+        _lib.lib().ssal_set_kernel_family(1)
+
+
 def test_interleaved_models_batches_and_shapes_match_the_single_stream_unfused_path(icnet19):
     """soak: ENet (3- and 4-channel handles) and ICNet share ONE process-wide pool of side streams; 40 back-to-back calls
     that interleave the models, the entry points (score / score with labels / forward), batch sizes 1..8 and frame sizes

@@ -169,3 +169,45 @@ def test_too_small_example_is_an_error(tmp_path):
     stage.init_iterator("x")
     with pytest.raises(ValueError, match="smaller"):
         stage.get_output()
+
+
+def test_copy_issued_skips_stale_ranges_of_dead_stages():
+    """a dead InputStage's stale (base, nbytes) range must not shadow a live stage's slot that the allocator placed inside
+    it: the scan drops the dead entry and keeps looking, and a stage's entries leave the table with the stage"""
+    import gc
+    import weakref
+    from semanticsegmentationactivelearning_amd.tensortools import input as inp
+
+    class FakeStage:
+        def __init__(self):
+            self._pin_events = {}
+
+    class FakeTensor:
+        def __init__(self, ptr):
+            self._p = ptr
+
+        def data_ptr(self):
+            return self._p
+
+    saved = dict(inp._PINNED_SLOTS)
+    inp._PINNED_SLOTS.clear()
+    try:
+        dead, live = FakeStage(), FakeStage()
+        inp._PINNED_SLOTS[1000] = (4096, weakref.ref(dead), 0)   # stale: covers [1000, 5096)
+        inp._PINNED_SLOTS[2000] = (1024, weakref.ref(live), 3)   # live slot inside the stale range
+        del dead
+        gc.collect()
+        assert inp.copy_issued(FakeTensor(2100), "ev") is True
+        assert live._pin_events == {3: ["ev"]}
+        assert 1000 not in inp._PINNED_SLOTS
+        assert inp.copy_issued(FakeTensor(9000), "ev") is False
+        # finalizer: a stage's own entries disappear with it
+        st = inp.InputStage(input_shape=[8, 8])
+        st._slot_bases.add(7000)
+        inp._PINNED_SLOTS[7000] = (64, weakref.ref(st), 0)
+        del st
+        gc.collect()
+        assert 7000 not in inp._PINNED_SLOTS
+    finally:
+        inp._PINNED_SLOTS.clear()
+        inp._PINNED_SLOTS.update(saved)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # throughput at the frame sizes the reference's own parameter files configure (conf/*.json:33-34), batch 8
 run() {
-  python bench.py "$@" --steps 96 --warmup 3 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "
+  python bench.py --full-line "$@" --steps 96 --warmup 3 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.readline()); r = d['roofline']['per_kernel_ms_per_batch']
 print('$*', '-> img/s %.1f' % d['value'], 'ms/step %.3f' % d['ms_per_step'], 'sum of kernel ms %.3f' % sum(r.values()))"

@@ -1341,7 +1341,7 @@ SSAL_API int ssal_debug_set_knob(const char *name, int value)
 // refuses to time a library whose knobs are not at their defaults
 SSAL_API int ssal_debug_get_knobs(char *json_out, int64_t cap)
 {
-    if (!json_out || cap < 240) return fail(SSAL_EINVAL, "json_out too small");
+    if (!json_out || cap < 320) return fail(SSAL_EINVAL, "json_out too small");
     const ssal::Knobs &k = ssal::knobs();
     int measure = 0, ablate = 0;
 #ifdef SSAL_MEASURE

@@ -501,11 +501,25 @@ ConvArgs conv_args(const float *x, int N, int H, int W, int Cin, const float *w,
 bool g_use_mfma = true;
 
 // Bottleneck.call (enet_modules.py:526-599)
+// size guards of the fused launchers (32-bit byte offsets inside one image)
+bool regular_fused(const DevLayer &L, int h, int w)
+{
+    return g_use_mfma && (long)h * w * L.cin <= (1L << 29) && bottleneck_mfma_supported(L.cin, L.f, L.asym);
+}
+bool down_fused(const DevLayer &L, int h, int w)
+{
+    return g_use_mfma && (long)h * w * L.cout < (1L << 31) && downsample_mfma_supported(L.cin, L.cout);
+}
+bool up_fused(const DevLayer &L, int h, int w)
+{
+    return g_use_mfma && (long)h * w * 4 * L.cout < (1L << 31) && upsample_mfma_supported(L.cin, L.cout);
+}
+
 hipError_t run_regular(const DevLayer &L, const float *x, int n, int h, int w, float *y,
                        const LayerTemps &T, hipStream_t s)
 {
     const int C = L.cin, f = L.f;
-    if (g_use_mfma && (long)h * w * C <= (1L << 29) && bottleneck_mfma_supported(C, f, L.asym))
+    if (regular_fused(L, h, w))
         return launch_bottleneck_mfma(x, y, n, h, w, C, L.dil, L.proj_w, L.proj_scale, L.proj_shift,
                                       L.proj_alpha, L.conv_w, L.asym ? L.conv_w1 : nullptr,
                                       L.conv_scale, L.conv_shift, L.conv_alpha, L.exp_w, L.exp_scale,
@@ -538,7 +552,7 @@ hipError_t run_down(const DevLayer &L, const float *x, int n, int h, int w, floa
                     const LayerTemps &T, hipStream_t s)
 {
     const int C = L.cin, f = L.f;
-    if (g_use_mfma && (long)h * w * L.cout < (1L << 31) && downsample_mfma_supported(C, L.cout))
+    if (down_fused(L, h, w))
         return launch_downsample_mfma(x, y, code, n, h, w, C, L.proj_w, L.proj_scale, L.proj_shift,
                                       L.proj_alpha, L.conv_w, L.conv_scale, L.conv_shift, L.conv_alpha,
                                       L.exp_w, L.exp_scale, L.exp_shift, L.res_alpha, s);
@@ -560,7 +574,7 @@ hipError_t run_up(const DevLayer &L, const float *x, int n, int h, int w, float 
                   const uint8_t *code, const int64_t *argmax, const LayerTemps &T, hipStream_t s)
 {
     const int C = L.cin, pf = L.f, cf = L.cf;
-    if (g_use_mfma && code && (long)h * w * 4 * L.cout < (1L << 31) && upsample_mfma_supported(C, L.cout))
+    if (code && up_fused(L, h, w))
         return launch_upsample_mfma(x, y, code, n, h, w, C, L.proj_w, L.proj_scale, L.proj_shift,
                                     L.proj_alpha, L.convT_stacked, L.conv_scale, L.conv_shift,
                                     L.conv_alpha, L.exp_w, L.exp_scale, L.exp_shift, L.res_w,

@@ -24,8 +24,10 @@ Rank 0 prints ONE JSON line (contract in the task statement) carrying
   `roofline_all`    the same figures for EVERY kernel symbol of the pass (avg us, algorithmic flops / bytes per launch,
                     bound, frac, PMC traffic per launch from the committed profiles/<round>_pmc passes),
   `score_digest`    SHA-256 of the float64 scores of the frames scored in the timed region, compared with the digest of
-                    the same frames in the committed table tests/golden/pool_scores.npz (a GPU run whose entries the
-                    parity tests tie to the C oracle); a mismatch makes the bench exit non-zero,
+                    the same frames in the committed table tests/golden/pool_scores.npz; a mismatch makes the bench exit
+                    non-zero.  The table is a REGRESSION PIN produced by the HIP path itself (tools/make_pool_scores.py),
+                    not oracle parity: what ties it to the C oracle is one frame per table (index 100) that the parity
+                    tests check against the oracle AND against the table entry, bit for bit,
   `secondary`       (N = 1) short legs of the other single-GPU BASELINE configs: c4 = configs[3] ICNet / margin,
                     c5 = configs[4] ENet RGB+NIR, 6 classes / entropy -- each with value, ms_per_step, roofline, digest,
   `cpu_baseline`    the torch-CPU restatement of the reference path, timed on this box's host cores (N = 1 only).

@@ -27,8 +27,15 @@ import torch.nn.functional as F
 EPSILON = float(np.finfo(np.float32).tiny)
 
 
+# Hooks of tests/test_split_operand_cpu.py (the accuracy side of the "beyond the fp32 wall" experiment): DTYPE = float64
+# turns the restatement into the fp64-accumulated evaluation; CONV2D / CONV_T2D swap the convolution primitive.
+DTYPE = torch.float32
+CONV2D = F.conv2d
+CONV_T2D = F.conv_transpose2d
+
+
 def _t(a):
-    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DTYPE)
 
 
 def _same_pad(size, k, stride, dil):
@@ -44,13 +51,13 @@ def conv2d_same(x, w_hwio, stride=1, dil=1):
     pl, pr = _same_pad(x.shape[3], kw, stride, dil)
     x = F.pad(x, (pl, pr, pt, pb))
     w = _t(w_hwio).permute(3, 2, 0, 1).contiguous()  # OIHW
-    return F.conv2d(x, w, stride=stride, dilation=dil)
+    return CONV2D(x, w, stride=stride, dilation=dil)
 
 
 def conv2d_transpose_3x3_s2(x, w_hwoi):
     """kernel [3,3,O,I] (TF) -> torch conv_transpose2d weight [I,O,3,3]; crop row/col 2H, 2W."""
     w = _t(w_hwoi).permute(3, 2, 0, 1).contiguous()
-    y = F.conv_transpose2d(x, w, stride=2, padding=0)
+    y = CONV_T2D(x, w, stride=2, padding=0)
     return y[:, :, : 2 * x.shape[2], : 2 * x.shape[3]].contiguous()
 
 

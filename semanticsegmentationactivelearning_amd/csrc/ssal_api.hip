@@ -1325,7 +1325,7 @@ SSAL_API int ssal_debug_probe(float *out_dev_256, void *stream)
 #ifdef SSAL_MEASURE  // measurement library only (csrc/ssal_measure_api.h)
 SSAL_API int ssal_debug_mfma_peak(int shape, int blocks, int iters, float *out_dev, void *stream)
 {
-    if (!out_dev || blocks <= 0 || iters <= 0 || (shape != 32 && shape != 16 && shape != 132 && shape != 232 && shape != 332 && shape != 432))
+    if (!out_dev || blocks <= 0 || iters <= 0 || (shape != 32 && shape != 16 && shape != 132 && shape != 232 && shape != 332 && shape != 432 && shape != 516 && shape != 616))
         return fail(SSAL_EINVAL, "bad arguments");
     HIP_TRY(launch_mfma_peak(shape, blocks, iters, out_dev, (hipStream_t)stream));
     return SSAL_OK;

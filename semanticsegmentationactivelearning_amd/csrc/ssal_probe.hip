@@ -334,6 +334,51 @@ __global__ __launch_bounds__(256) void k_mfma_peak(float *out, int iters)
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += v[k];
         out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3] + t;
+    } else if (SHAPE == 516 || SHAPE == 616) {
+        // "beyond the fp32 wall" probe (measurement library only, nothing of it ships): one K = 16
+        // step of a 32x32 fp32 GEMM tile as SIX v_mfma_f32_32x32x16_bf16 on operands split into three bf16 terms each
+        // (x = x1 + x2 + x3 exactly by truncation; products x1w1, x1w2, x2w1, x1w3, x2w2, x3w1 accumulated in fp32 --
+        // what is dropped is O(2^-24) relative).  516: the activation operand is split in registers every step (the form a
+        // kernel fed with fp32 tensors needs: 4 and / sub + 1.5 v_perm per value); 616: both operands arrive pre-split
+        // (weights, or a tensor its producer stored as three bf16 planes).  Reported as fp32-EQUIVALENT flops: 2*32*32*16
+        // per step.
+        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+        f32x16 c0 = {0};
+        unsigned xr[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xr[k] = __float_as_uint(a + 0.37f * k);
+        uint4 w1 = make_uint4(0x3f803f80u, 0x3f813f7fu, 0x3f823f7eu, 0x3f833f7du), w2 = w1, w3 = w1;
+        w2.x ^= threadIdx.x; w3.y ^= threadIdx.x;
+        uint4 p1 = w1, p2 = w2, p3 = w3;
+        for (int i = 0; i < iters; ++i) {
+            if (SHAPE == 516) {
+                unsigned t1[8], t2[8], t3[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const unsigned x = xr[k] + (unsigned)i;            // a new value every step: nothing to hoist
+                    const unsigned h1 = x & 0xffff0000u;
+                    const float r1 = __uint_as_float(x) - __uint_as_float(h1);
+                    const unsigned h2 = __float_as_uint(r1) & 0xffff0000u;
+                    const float r2 = r1 - __uint_as_float(h2);
+                    t1[k] = h1; t2[k] = h2; t3[k] = __float_as_uint(r2);
+                }
+                auto pack = [](unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); };
+                p1 = make_uint4(pack(t1[0], t1[1]), pack(t1[2], t1[3]), pack(t1[4], t1[5]), pack(t1[6], t1[7]));
+                p2 = make_uint4(pack(t2[0], t2[1]), pack(t2[2], t2[3]), pack(t2[4], t2[5]), pack(t2[6], t2[7]));
+                p3 = make_uint4(pack(t3[0], t3[1]), pack(t3[2], t3[3]), pack(t3[4], t3[5]), pack(t3[6], t3[7]));
+            } else {
+                p1.x += 1u;  // keep the operands loop-variant
+            }
+            const bf16x8 a1 = __builtin_bit_cast(bf16x8, p1), a2 = __builtin_bit_cast(bf16x8, p2), a3 = __builtin_bit_cast(bf16x8, p3);
+            const bf16x8 b1 = __builtin_bit_cast(bf16x8, w1), b2 = __builtin_bit_cast(bf16x8, w2), b3 = __builtin_bit_cast(bf16x8, w3);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, c0, 0, 0, 0);  // small terms first
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, c0, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, c0, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, c0, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, c0, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c0, 0, 0, 0);
+        }
+        out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c0[5];
     } else if (SHAPE == 232) {
         f32x16 c0 = {0};
         float p = a, q = b;
@@ -354,17 +399,23 @@ __global__ __launch_bounds__(256) void k_mfma_peak(float *out, int iters)
 hipError_t launch_mfma_peak(int shape, int blocks, int iters, float *out, hipStream_t s)
 {
     const bool is32 = shape != 16;
-    const double flop = (double)blocks * 4 /*waves*/ * iters * 4.0 * (is32 ? 4096.0 : 2048.0);
+    const bool split = shape == 516 || shape == 616;  // one K = 16 step of a 32x32 tile per iteration: 2 * 32 * 32 * 16 flops
+    const double flop = (double)blocks * 4 /*waves*/ * iters * (split ? 32768.0 : 4.0 * (is32 ? 4096.0 : 2048.0));
     const char *nm = shape == 32 ? "k_mfma_peak<32x32x2 4acc>" : shape == 132 ? "k_mfma_peak<32x32x2 1chain>"
                    : shape == 232 ? "k_mfma_peak<32x32x2 1chain+swap>"
                    : shape == 332 ? "k_mfma_peak<32x32x2 4acc + 8 v_fma / 4 mfma>"
-                   : shape == 432 ? "k_mfma_peak<32x32x2 4acc + 16 v_fma / 4 mfma>" : "k_mfma_peak<16x16x4 4acc>";
+                   : shape == 432 ? "k_mfma_peak<32x32x2 4acc + 16 v_fma / 4 mfma>"
+                   : shape == 516 ? "k_mfma_peak<bf16x3: 6 x 32x32x16_bf16 per K=16 step, operand split in registers> (fp32-equivalent)"
+                   : shape == 616 ? "k_mfma_peak<bf16x3: 6 x 32x32x16_bf16 per K=16 step, operands pre-split> (fp32-equivalent)"
+                   : "k_mfma_peak<16x16x4 4acc>";
     ProfScope prof(nm, flop, 0.0, s);
     if (shape == 32) hipLaunchKernelGGL(k_mfma_peak<32>, dim3(blocks), dim3(256), 0, s, out, iters);
     else if (shape == 132) hipLaunchKernelGGL(k_mfma_peak<132>, dim3(blocks), dim3(256), 0, s, out, iters);
     else if (shape == 232) hipLaunchKernelGGL(k_mfma_peak<232>, dim3(blocks), dim3(256), 0, s, out, iters);
     else if (shape == 332) hipLaunchKernelGGL(k_mfma_peak<332>, dim3(blocks), dim3(256), 0, s, out, iters);
     else if (shape == 432) hipLaunchKernelGGL(k_mfma_peak<432>, dim3(blocks), dim3(256), 0, s, out, iters);
+    else if (shape == 516) hipLaunchKernelGGL(k_mfma_peak<516>, dim3(blocks), dim3(256), 0, s, out, iters);
+    else if (shape == 616) hipLaunchKernelGGL(k_mfma_peak<616>, dim3(blocks), dim3(256), 0, s, out, iters);
     else hipLaunchKernelGGL(k_mfma_peak<16>, dim3(blocks), dim3(256), 0, s, out, iters);
     return hipGetLastError();
 }

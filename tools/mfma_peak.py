@@ -8,9 +8,9 @@ import torch
 from semanticsegmentationactivelearning_amd import _lib
 L = _lib.lib()
 out = torch.zeros(4096 * 256, device="cuda")
-for shape in (32, 132, 232, 332, 432, 16):
+for shape in (32, 132, 232, 332, 432, 16, 516, 616):
     for blocks in (256, 512, 768):
-        iters = 40000 if shape == 16 else 20000
+        iters = 40000 if shape in (16, 516, 616) else 20000
         _lib.check(L.ssal_debug_mfma_peak(shape, blocks, 1000, _lib.dev_ptr(out), _lib.stream_ptr()))  # warm
         torch.cuda.synchronize()
         _lib.profile_enable(True)

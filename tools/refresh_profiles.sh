@@ -4,8 +4,8 @@
 # the PMC passes for both models.
 set -u
 OUT=gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
-timeout -k 10 900 python bench.py > $OUT/bench_enet_full.json 2> $OUT/bench_enet_full.log; rc=$?; echo "enet bench rc=$rc"; [ $rc -ge 124 ] && exit $rc
-timeout -k 10 600 python bench.py --model icnet --steps 120 --warmup 3 > $OUT/bench_icnet.json 2> $OUT/bench_icnet.log; rc=$?; echo "icnet bench rc=$rc"; [ $rc -ge 124 ] && exit $rc
+timeout -k 10 900 python bench.py --detail-file $OUT/bench_enet_full_detail.json > $OUT/bench_enet_full.json 2> $OUT/bench_enet_full.log; rc=$?; echo "enet bench rc=$rc"; [ $rc -ge 124 ] && exit $rc
+timeout -k 10 600 python bench.py --model icnet --steps 120 --warmup 3 --detail-file $OUT/bench_icnet_detail.json > $OUT/bench_icnet.json 2> $OUT/bench_icnet.log; rc=$?; echo "icnet bench rc=$rc"; [ $rc -ge 124 ] && exit $rc
 for M in enet icnet; do
   # kernel stats of whole-batch launches on one stream (img_groups=1: the launch shape of the bench's roofline leg) ...
   timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_final_$M -- python3 bench.py --model $M --steps 40 --warmup 2 --no-cpu-baseline --no-secondary --no-roofline --knob img_groups=1 --allow-nondefault-knobs > $OUT/rocprof_final_$M.log 2>&1; rc=$?; echo "rocprof $M rc=$rc"; [ $rc -ge 124 ] && exit $rc

@@ -191,7 +191,9 @@ int ssal_set_kernel_family(int use_mfma);
  * semantics): writes 256 floats */
 int ssal_debug_probe(float *out_dev_256, void *stream);
 
-/* tuning / A-B knob of the fused bottleneck launchers ("bnk_tw": 16 forces 8x16 tiles, "bnk_xcd": 0 switches the
+/* tuning / A-B knob of the fused bottleneck launchers ("bnk_tw": 16 forces 8x16 tiles, "bnk_o4": the four-workgroups-per-CU
+ * form of the regular 128-channel block -- 2 (default) where the phase sub-image is at most 16 pixels wide, 1 everywhere,
+ * 0 never --, "bnk_xcd": 0 switches the
  * XCD-aware tile order off, "img_groups": G runs the layers selected by "img_span" (default 4 = Initial .. Final + score) as G image
  * groups on G library-owned side streams, forked from / joined into the caller's stream with events -- default 2, 1 =
  * everything on the caller's stream).  Every setting produces bit-identical results (tests/test_gpu_parity.py); SSAL_EINVAL for
@@ -199,7 +201,7 @@ int ssal_debug_probe(float *out_dev_256, void *stream);
  * ablation ("ablate") and the SSAL_* environment defaults exist only in -DSSAL_MEASURE builds (tools/phase_trace.py),
  * whose ssal_version() says so. */
 int ssal_debug_set_knob(const char *name, int value);
-/* JSON object with the state of every switch that can change what a launch does or costs: kernel_family, bnk_tw,
+/* JSON object with the state of every switch that can change what a launch does or costs: kernel_family, bnk_tw, bnk_o4,
  * bnk_xcd, img_groups, img_span, fuse_ends, img_lag, ig_div, ablate, measure_build, profiling, defaults (1 iff all are at their shipping values).  bench.py prints it
  * in its result line and refuses to time anything else. */
 int ssal_debug_get_knobs(char *json_out, int64_t cap);

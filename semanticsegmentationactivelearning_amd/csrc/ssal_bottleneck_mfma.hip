@@ -407,6 +407,186 @@ __global__ __launch_bounds__(256, 3) void k_bottleneck_mfma(BnkArgs a)
     tr.flush(a.trace, lane, wave);
 }
 
+// ---- the same block at FOUR workgroups per CU (experiment of round 4, knob bnk_o4): 8x16 tiles, <= 128 VGPRs, 40 KB of
+// LDS.  What makes the registers fit: the projection kernel (16 KB) lives in LDS in B-operand order -- float4 (s4, lane) =
+// Wp[2(4 s4 + i) + h][j], i = 0..3, one conflict-free ds_read_b128 per four MFMAs instead of 40 resident + 24 re-fetched
+// registers -- and after the projection the same 16 KB hold the EXPANSION kernel (ds_read instead of two 16-register
+// prefetch buffers fed from L1).  P needs 180 rows for a 10 x 18 halo'd tile: 24 480 + 16 384 = 40 864 of the 40 960
+// bytes a quarter of the CU's LDS offers.
+constexpr int O4_PROWS = 180;
+__global__ __launch_bounds__(256, 4) void k_bottleneck_o4(BnkArgs a)
+{
+    constexpr int TW = 16, HWP = TW + 2;
+    __shared__ float P[O4_PROWS * PSTR];
+    __shared__ __attribute__((aligned(16))) float WL[C * F];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const TileId t = decode_tile<TW>(a);
+    if (t.empty) return;
+    const int d = a.dil;
+    const float *ximg = a.x + (long)t.n * a.H * a.W * C;
+    float *yimg = a.y + (long)t.n * a.H * a.W * C;
+    PhaseTrace tr;
+    tr.mark(0);
+    // ---- phase A: projection of the 10 x 18 halo'd tile (6 M-tiles: waves 0, 1 take two).  The activation fragments of
+    // a wave's FIRST M-tile are requested before anything else, so that their HBM round trip runs beside the kernel
+    // fill and the barrier; those of its second M-tile as soon as the first one's MFMAs have consumed the registers.
+    constexpr int npix_halo = 10 * HWP;
+    float4 X[16];
+    unsigned long long vmask = 0ull;
+    auto request = [&](int mt) {  // -> vmask of the M-tile; X = its 16 fragments (not requested for an all-outside M-tile)
+        const int q = mt * 32 + j;
+        const int hr = q / HWP, hc = q - hr * HWP;
+        const int pr = t.ty0 - 1 + hr, pc = t.tx0 - 1 + hc;
+        const bool valid = (q < npix_halo) && (pr >= 0) && (pr < t.Hp) && (pc >= 0) && (pc < t.Wp);
+        vmask = __ballot(valid);
+        if (vmask == 0ull) return;
+        const float *xp = valid ? ximg + ((long)(t.py + pr * d) * a.W + (t.px + pc * d)) * C : ximg;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) X[u] = *reinterpret_cast<const float4 *>(xp + (2 * u + h) * 4);
+    };
+    request(wave);
+    // projection kernel -> LDS: element (k, co) of Wp[128][32] goes to float4 group (s >> 2, h, co), slot s & 3 (k = 2s + h)
+#pragma unroll
+    for (int it = 0; it < C * F / 256; ++it) {
+        const int e = (int)threadIdx.x + 256 * it, k = e >> 5, co = e & 31, s_ = k >> 1;
+        WL[(((s_ >> 2) * 64 + (k & 1) * 32 + co) << 2) + (s_ & 3)] = a.wp[e];
+    }
+    const float bs = a.ps[j], bt = a.pt[j], ba = a.pa[j];
+    __syncthreads();
+    for (int mt = wave; mt < (npix_halo + 31) / 32; mt += 4) {
+        if (mt != wave) request(mt);
+        const unsigned long long vm64 = vmask;
+        if (vm64 == 0ull) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int qi = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (qi < O4_PROWS) P[qi * PSTR + kperm(j)] = 0.0f;
+            }
+            continue;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc = {0};
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            asm volatile("" ::: "memory");  // keep the read here: hoisted out of the M-tile loop it would pin 64 registers
+            const float4 w = *reinterpret_cast<const float4 *>(WL + ((u * 64 + lane) << 2));  // steps 4u .. 4u+3
+            float a0 = X[u].x, a1 = X[u].y, a2 = X[u].z, a3 = X[u].w;
+            swap32(a0, a1);
+            swap32(a2, a3);
+            acc = mfma32(a0, w.x, acc);
+            acc = mfma32(a2, w.y, acc);
+            acc = mfma32(a1, w.z, acc);
+            acc = mfma32(a3, w.w, acc);
+        }
+        const unsigned vmh = (unsigned)vm64 >> (4 * h);  // validity is per pixel: both lane halves carry the same 32 bits
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r0 = (i & 3) + 8 * (i >> 2), ri = r0 + 4 * h;
+            const bool ok = (vmh >> r0) & 1u;
+            const float v = ok ? prelu1(fmaf(acc[i], bs, bt), ba) : 0.0f;
+            if (mt * 32 + ri < O4_PROWS) P[(mt * 32 + ri) * PSTR + kperm(j)] = v;
+        }
+    }
+    // this thread's 16 elements of the expansion kernel We[32][128] (L2 hits), requested before the barrier and written
+    // over WL behind it: element (ci, co) goes to float4 group (nt, s >> 2, h, j), slot s & 3 (ci = 2s + h, co = 32 nt + j)
+    float wex[C * F / 256];
+#pragma unroll
+    for (int it = 0; it < C * F / 256; ++it) wex[it] = a.we[(int)threadIdx.x + 256 * it];
+    tr.mark(1);
+    __syncthreads();  // P complete, the projection kernel no longer needed
+    tr.mark(2);
+#pragma unroll
+    for (int it = 0; it < C * F / 256; ++it) {
+        const int e = (int)threadIdx.x + 256 * it, ci = e >> 7, co = e & 127, s_ = ci >> 1;
+        WL[((((co >> 5) * 4 + (s_ >> 2)) * 64 + (ci & 1) * 32 + (co & 31)) << 2) + (s_ & 3)] = wex[it];
+    }
+
+    // ---- phase B: one output M-tile per wave (tile rows 2 wave, 2 wave + 1)
+    const int mt = wave;
+    constexpr unsigned kOOB = 0x80000000u;
+    const unsigned img_bytes = (unsigned)(a.H * a.W * C) * 4u;
+    const rsrc_t xrs = make_rsrc(ximg, img_bytes), yrs = make_rsrc(yimg, img_bytes);
+    const rsrc_t esrs = make_rsrc(a.es, C * 4), etrs = make_rsrc(a.et, C * 4), rars = make_rsrc(a.ra, C * 4);
+    unsigned boff[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int ti = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        const int rr = ti / TW, cc = ti - rr * TW;
+        const int pr = t.ty0 + rr, pc = t.tx0 + cc;
+        const bool ok = (pr < t.Hp) && (pc < t.Wp);
+        boff[i] = ok ? (unsigned)((((t.py + pr * d) * a.W + (t.px + pc * d)) * C + j) * 4) : kOOB;
+    }
+    float rxA[16], rxB[16];
+    auto fetch_rx = [&](int nt, float (&rx)[16]) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rx[i] = bload(xrs, boff[i], nt * 128);
+    };
+    fetch_rx(0, rxA);  // the first residual rows travel while the convolution runs
+    float qv[16];
+    conv_tile_q<TW, 3, 3, HWP>(a, P, a.wc, mt, j, h, qv);
+    tr.mark(3);
+    fetch_rx(1, rxB);
+    __syncthreads();  // the expansion kernel is in WL (written by every thread before its convolution)
+    float sA, tA, aA, sB, tB, aB;
+    auto fetch_bn = [&](int nt, float &s1, float &t1, float &al) {
+        s1 = bload(esrs, j * 4, nt * 128); t1 = bload(etrs, j * 4, nt * 128); al = bload(rars, j * 4, nt * 128);
+    };
+    auto chain_step = [&](int nt, int s4, f32x16 e) {  // four MFMAs: steps 4 s4 .. 4 s4 + 3 of N-tile nt
+        asm volatile("" ::: "memory");
+        const float4 w = *reinterpret_cast<const float4 *>(WL + (((nt * 4 + s4) * 64 + lane) << 2));
+        e = mfma32(qv[ord(4 * s4 + 0)], w.x, e);
+        e = mfma32(qv[ord(4 * s4 + 1)], w.y, e);
+        e = mfma32(qv[ord(4 * s4 + 2)], w.z, e);
+        e = mfma32(qv[ord(4 * s4 + 3)], w.w, e);
+        return e;
+    };
+    auto put = [&](int nt, int i, float v) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, boff[i], nt * 128, 0);
+    };
+    fetch_bn(0, sA, tA, aA);
+    fetch_bn(1, sB, tB, aB);
+    f32x16 e0 = {0}, e1 = {0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) e0 = chain_step(0, s4, e0);
+    // stage 1: chain of N-tile 1  ||  epilogue of N-tile 0
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        e1 = chain_step(1, s4, e1);
+#pragma unroll
+        for (int i = 4 * s4; i < 4 * s4 + 4; ++i) put(0, i, prelu1(fmaf(e0[i], sA, tA) + rxA[i], aA));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_rx(2, rxA);
+    fetch_bn(2, sA, tA, aA);
+    e0 = (f32x16){0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        e0 = chain_step(2, s4, e0);
+#pragma unroll
+        for (int i = 4 * s4; i < 4 * s4 + 4; ++i) put(1, i, prelu1(fmaf(e1[i], sB, tB) + rxB[i], aB));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_rx(3, rxB);
+    fetch_bn(3, sB, tB, aB);
+    e1 = (f32x16){0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        e1 = chain_step(3, s4, e1);
+#pragma unroll
+        for (int i = 4 * s4; i < 4 * s4 + 4; ++i) put(2, i, prelu1(fmaf(e0[i], sA, tA) + rxA[i], aA));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) put(3, i, prelu1(fmaf(e1[i], sB, tB) + rxB[i], aB));
+    tr.mark(4);
+#ifdef SSAL_PHASE_TRACE
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    tr.mark(7);
+    tr.flush(a.trace, lane, wave);
+}
+
 // asymmetric bottleneck: (5,1) then (1,5) with no BN / activation in between (dilation 1).
 // LDS: P = the projected tile with a 2-pixel halo (12 x 36 pixels), R = a ring of RROWS pixel slots of the (5,1)
 // result: the tile is finished in two halves, which keeps the workgroup at 80.5 KB of LDS = two workgroups per
@@ -1006,6 +1186,7 @@ Knobs &knobs()
     static Knobs k = [] {
         Knobs q;
         q.bnk_tw = 0;
+        q.bnk_o4 = 2;
         q.bnk_xcd = 1;
         q.img_groups = 2;
         q.img_span = 4;
@@ -1147,7 +1328,10 @@ hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W,
     if (Cin != C) return launch_bottleneck_mfma16(a, Cin, s);
     a.TH = 8;
     const int Hp = (H + dil - 1) / dil, Wp = (W + dil - 1) / dil;  // largest phase sub-image
-    const bool wide = Wp > 16 && kn.bnk_tw != 16;
+    // 8x16 tiles at four workgroups per CU (k_bottleneck_o4): bnk_o4 = 1 everywhere (experiment), 2 = only where the phase
+    // sub-image is at most 16 pixels wide, i.e. where 8x16 tiles are used anyway (the dilation-16 layers at 128 x 256)
+    const bool o4 = !asym && Cin == C && (kn.bnk_o4 == 1 || (kn.bnk_o4 == 2 && Wp <= 16));
+    const bool wide = Wp > 16 && kn.bnk_tw != 16 && !o4;
     const int TW = wide ? 32 : 16;
     a.tiles_y = (Hp + a.TH - 1) / a.TH;
     a.tiles_x = (Wp + TW - 1) / TW;
@@ -1162,7 +1346,7 @@ hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W,
     const double taps = asym ? 10.0 : 9.0;
     // one profile row per kernel symbol, as rocprofv3 lists them
     ProfScope prof(asym ? (wide ? "k_bottleneck_mfma_asym<32>" : "k_bottleneck_mfma_asym<16>")
-                        : (wide ? "k_bottleneck_mfma<32>" : "k_bottleneck_mfma<16>"),
+                        : o4 ? "k_bottleneck_o4" : (wide ? "k_bottleneck_mfma<32>" : "k_bottleneck_mfma<16>"),
                    2.0 * pix * (Cin * f + taps * f * f + f * Cin),
                    4.0 * (2.0 * pix * Cin + Cin * f * 2.0 + taps * f * f), s);
     if (asym) {
@@ -1170,6 +1354,8 @@ hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W,
             hipLaunchKernelGGL(k_bottleneck_mfma_asym<32>, dim3((unsigned)launch_grid), dim3(256), 0, s, a);
         else
             hipLaunchKernelGGL(k_bottleneck_mfma_asym<16>, dim3((unsigned)launch_grid), dim3(256), 0, s, a);
+    } else if (o4) {
+        hipLaunchKernelGGL(k_bottleneck_o4, dim3((unsigned)launch_grid), dim3(256), 0, s, a);
     } else {
         if (wide)
             hipLaunchKernelGGL(k_bottleneck_mfma<32>, dim3((unsigned)launch_grid), dim3(256), 0, s, a);

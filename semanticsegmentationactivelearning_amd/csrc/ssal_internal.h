@@ -117,6 +117,7 @@ hipError_t launch_upsample_mfma(const float *x, float *y, const uint8_t *code, i
 // -DSSAL_MEASURE builds).
 struct Knobs {
     int bnk_tw;      // 16 = force 8x16 tiles in the 128-channel bottleneck kernels
+    int bnk_o4;      // k_bottleneck_o4 (8x16 tiles, four workgroups per CU): 2 (default) = where the phase sub-image is <= 16 wide, 1 = everywhere, 0 = never
     int bnk_xcd;     // 1 = XCD-aware tile order in the 128-channel bottleneck kernels
     int fuse_ends;   // bit 0: Initial + Bottleneck1_0 in one launch; bit 1: Bottleneck5_1 inside Final + score (ranking pass); default 3
     int ig_div;      // ICNet: the ">= 512 workgroups per launch" rules of k_igemm / k_conv3x3_c32 use 512 / ig_div; 0 (default) = the number of image-group chains of the call

@@ -286,9 +286,15 @@ def test_bottleneck_tile_shapes_bit_identical(enet_c3k19, name):
         _lib.set_knob("bnk_xcd", 0)
         got = layer(xd, training=False)
         assert torch.equal(got, ref), "plain tile order differs from the XCD-aware order"
+        _lib.set_knob("bnk_xcd", 1)
+        for o4 in (0, 1):  # default 2: k_bottleneck_o4 only where the phase sub-image is at most 16 pixels wide (3_8 here)
+            _lib.set_knob("bnk_o4", o4)
+            got = layer(xd, training=False)
+            assert torch.equal(got, ref), "bnk_o4=%d (k_bottleneck_o4: 8x16 tiles, four workgroups per CU) differs" % o4
     finally:
         _lib.set_knob("bnk_tw", 0)
         _lib.set_knob("bnk_xcd", 1)
+        _lib.set_knob("bnk_o4", 2)
     want = orc.bottleneck(P, name, x[1:2], dil=layer.dilation_rate[0], asym=layer.asymmetric)
     report_diff(name + " [128,256] vs oracle (bit-exact)", ref[1:2].cpu().numpy(), want)
 

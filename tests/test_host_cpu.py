@@ -343,10 +343,10 @@ def test_bench_scaling_default_and_common_step_count():
 
 def test_bench_kernel_roofline_rows_and_committed_pmc():
     """bench.kernel_roofline: bound from the arithmetic intensity against the fp32 ridge, achieved / frac per launch, PMC
-    traffic per launch from the newest committed pass (profiles/r03_pmc); packed-vector kernels are labelled as such"""
+    traffic per launch from the newest committed pass (profiles/r04_pmc); packed-vector kernels are labelled as such"""
     import bench
     rnd, pmc = bench.load_pmc("enet")
-    assert rnd == "r03" and "k_bottleneck_mfma<32>" in pmc and "k_final_score<fused 5_1>" in pmc and "k_initial_down16" in pmc
+    assert rnd == "r04" and "k_bottleneck_mfma<32>" in pmc and "k_final_score<fused 5_1>" in pmc and "k_initial_down16" in pmc
     d = {"launches": 30, "ms": 30 * 0.114, "flops": 30 * 9.127e9, "bytes": 30 * 268.5e6}
     r = bench.kernel_roofline("k_bottleneck_mfma<32>", d, 3, pmc["k_bottleneck_mfma<32>"])
     assert r["bound"] == "mfma" and r["pipe"] == "mfma" and r["launches_per_batch"] == 10 and abs(r["avg_us"] - 114.0) < 1e-6

@@ -445,7 +445,8 @@ __global__ __launch_bounds__(256, 4) void k_bottleneck_o4(BnkArgs a)
 #pragma unroll
         for (int u = 0; u < 16; ++u) X[u] = *reinterpret_cast<const float4 *>(xp + (2 * u + h) * 4);
     };
-    request(wave);
+    const int mt0 = wave;
+    request(mt0);
     // projection kernel -> LDS: element (k, co) of Wp[128][32] goes to float4 group (s >> 2, h, co), slot s & 3 (k = 2s + h)
 #pragma unroll
     for (int it = 0; it < C * F / 256; ++it) {
@@ -454,8 +455,8 @@ __global__ __launch_bounds__(256, 4) void k_bottleneck_o4(BnkArgs a)
     }
     const float bs = a.ps[j], bt = a.pt[j], ba = a.pa[j];
     __syncthreads();
-    for (int mt = wave; mt < (npix_halo + 31) / 32; mt += 4) {
-        if (mt != wave) request(mt);
+    for (int mt = mt0; mt < (npix_halo + 31) / 32; mt += 4) {
+        if (mt != mt0) request(mt);
         const unsigned long long vm64 = vmask;
         if (vm64 == 0ull) {
 #pragma unroll

@@ -207,10 +207,12 @@ class DeviceState:
     The model provides ``_create_handle(L) -> c_void_p``, ``_push_tensors(L, handle)`` (set_tensor + commit),
     ``_destroy_handle(L, handle)`` and ``variables``."""
 
+    MAX_WORKSPACES = 4  # live (device, stream) workspaces per model; the least recently used one is released beyond that
+
     def _init_device_state(self):
         import threading
         self._handles = {}        # device ordinal -> [handle, pushed_versions]
-        self._workspaces = {}     # (device ordinal, stream pointer) -> uint8 tensor
+        self._workspaces = {}     # (device ordinal, stream pointer) -> uint8 tensor, in least-recently-used order
         self._ws = None
         self._last_dims = None
         self._state_lock = threading.Lock()
@@ -244,15 +246,25 @@ class DeviceState:
         torch = require_gpu()
         key = (device.index if device.index is not None else torch.cuda.current_device(),
                torch.cuda.current_stream(device).cuda_stream)
-        ws = self._workspaces.get(key)
-        if ws is None or ws.numel() < nbytes:
-            self._workspaces.pop(key, None)  # release before growing
-            if self._ws is ws:
-                self._ws = None
-            del ws
-            ws = self._workspaces[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        self._ws = ws
-        return ws
+        with self._state_lock:
+            ws = self._workspaces.pop(key, None)
+            if ws is None or ws.numel() < nbytes:
+                if self._ws is ws:
+                    self._ws = None
+                del ws  # release before growing
+                # a workspace is 1.8 GB at batch 8 x 1024 x 2048: a caller that cycles through many streams must not pin
+                # one per stream for ever.  Dropping the tensor is safe while its stream still runs: the caching
+                # allocator hands a block back only to allocations made on the stream it was allocated on
+                while len(self._workspaces) >= self.MAX_WORKSPACES:
+                    old_key = next(iter(self._workspaces))
+                    old = self._workspaces.pop(old_key)
+                    if self._ws is old:
+                        self._ws = None
+                    del old
+                ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            self._workspaces[key] = ws  # most recently used last
+            self._ws = ws
+            return ws
 
     def _release_device_state(self):
         try:

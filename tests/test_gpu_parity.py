@@ -1011,7 +1011,24 @@ def test_two_host_threads_share_one_handle(enet_c3k19):
         assert len(results[t]) == 24
         for r in results[t]:
             assert np.array_equal(r.cpu().numpy(), want[t]), (t, r.cpu().numpy(), want[t])
-    assert len(net._workspaces) >= 3  # main stream + one workspace per worker stream
+    assert 3 <= len(net._workspaces) <= net.MAX_WORKSPACES  # main stream + one workspace per worker stream
+
+
+def test_workspaces_per_stream_are_bounded(enet_c3k19):
+    """one workspace per (device, stream) keeps concurrent callers apart; a caller that cycles through many streams must not
+    pin one workspace per stream for ever: at most DeviceState.MAX_WORKSPACES stay alive, results unchanged"""
+    net, _ = enet_c3k19
+    x = syn.synth_frames_device(21, 2, 64, 128, 3)
+    want = net.score(x, "entropy").cpu().numpy()
+    streams = [torch.cuda.Stream() for _ in range(7)]
+    for rep in range(2):
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                got = net.score(x, "entropy")
+            st.synchronize()
+            assert np.array_equal(got.cpu().numpy(), want)
+            assert len(net._workspaces) <= net.MAX_WORKSPACES
 
 
 def test_failed_call_leaves_no_chain_running(enet_c3k19):

@@ -24,7 +24,7 @@ CFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract
 FLAGS = CFLAGS + ["-shared"]  # one-shot form (tools/phase_trace.py builds its measurement variant with it)
 
 
-MEASURE_ONLY = ("ssal_probe.hip",)  # copy / MFMA probes: measurement libraries only (tools/phase_trace.py)
+MEASURE_ONLY = ("ssal_probe.hip", "ssal_split_probe.hip")  # copy / MFMA probes, the bf16x3 split-operand bottleneck: measurement libraries only (tools/phase_trace.py)
 
 
 def sources(measure=False):

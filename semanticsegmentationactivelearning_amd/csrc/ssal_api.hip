@@ -1347,6 +1347,7 @@ SSAL_API int ssal_debug_set_knob(const char *name, int value)
     else if (n == "ig_div") k.ig_div = value > 0 ? value : 0;
 #ifdef SSAL_MEASURE
     else if (n == "ablate") k.ablate = value;
+    else if (n == "bnk_split") k.bnk_split = value;
 #endif
     else return fail(SSAL_EINVAL, "unknown knob '%s'", name);
     return SSAL_OK;
@@ -1361,7 +1362,7 @@ SSAL_API int ssal_debug_get_knobs(char *json_out, int64_t cap)
     int measure = 0, ablate = 0;
 #ifdef SSAL_MEASURE
     measure = 1;
-    ablate = k.ablate;
+    ablate = k.ablate + 100 * k.bnk_split;  // any non-zero value makes `defaults` 0: bench.py refuses to time it as a result
 #endif
     const int dflt = g_use_mfma && k.bnk_tw == 0 && k.bnk_o4 == 2 && k.bnk_xcd == 1 && k.img_groups == 2 && k.img_span == 4 && k.fuse_ends == 3 && k.img_lag == 0 && k.ig_div == 0 && ablate == 0 && !ssal::prof_enabled()
                      && ssal::g_trace_buf == nullptr;

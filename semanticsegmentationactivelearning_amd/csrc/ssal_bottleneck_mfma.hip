@@ -1199,6 +1199,7 @@ Knobs &knobs()
         q.bnk_tw = env("SSAL_BNK_TW", 0);
         q.bnk_xcd = env("SSAL_BNK_XCD", 1);
         q.ablate = env("SSAL_ABLATE", 0);
+        q.bnk_split = env("SSAL_BNK_SPLIT", 0);
         q.img_groups = env("SSAL_IMG_GROUPS", 2);
         q.fuse_ends = env("SSAL_FUSE_ENDS", 3);
 #endif
@@ -1327,6 +1328,9 @@ hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W,
 #endif
     a.trace = nullptr;
     if (Cin != C) return launch_bottleneck_mfma16(a, Cin, s);
+#ifdef SSAL_MEASURE
+    if (kn.bnk_split && !asym) return launch_bottleneck_split(a, s);  // bf16x3 probe: results differ in the last bits
+#endif
     a.TH = 8;
     const int Hp = (H + dil - 1) / dil, Wp = (W + dil - 1) / dil;  // largest phase sub-image
     // 8x16 tiles at four workgroups per CU (k_bottleneck_o4): bnk_o4 = 1 everywhere (experiment), 2 = only where the phase

@@ -126,6 +126,7 @@ struct Knobs {
     int img_groups;  // ENet: the layers of img_span run as this many image groups on side streams (default 2; 1 = everything on the caller's stream)
 #ifdef SSAL_MEASURE
     int ablate;      // measurement builds only: 1 = stop after the projection phase, 2 = skip it (results invalid)
+    int bnk_split;   // measurement builds only: 1 = the regular 128-channel bottleneck on bf16x3 split operands (ssal_split_probe.hip; NOT bit-identical)
 #endif
 };
 Knobs &knobs();
@@ -156,6 +157,10 @@ struct ChainSet {
 extern unsigned long long *g_trace_buf;
 extern long g_trace_bytes;
 hipError_t launch_probe_swap(float *out, hipStream_t s);
+#ifdef SSAL_MEASURE
+struct BnkArgs;
+hipError_t launch_bottleneck_split(const BnkArgs &a, hipStream_t s);  // ssal_split_probe.hip (measurement libraries only)
+#endif
 hipError_t launch_copy_probe(int mode, const float *x, float *y, int N, int H, int W, int spin, hipStream_t s);
 hipError_t launch_mfma_peak(int shape, int blocks, int iters, float *out, hipStream_t s);
 

@@ -432,13 +432,18 @@ __global__ __launch_bounds__(256, 4) void k_bottleneck_o4(BnkArgs a)
     // a wave's FIRST M-tile are requested before anything else, so that their HBM round trip runs beside the kernel
     // fill and the barrier; those of its second M-tile as soon as the first one's MFMAs have consumed the registers.
     constexpr int npix_halo = 10 * HWP;
+    // A tile that IS a whole phase sub-image (every tile of the dilation-16 layers at 128 x 256: sub-images of 8 x 16) has
+    // its entire halo ring outside the image: the ring is exact zeros, and only the 128 centre pixels are projected --
+    // 4 M-tiles, one per wave, instead of the 6 of the halo'd walk (workgroup-uniform).
+    const bool whole = t.ty0 == 0 && t.tx0 == 0 && t.Hp <= 8 && t.Wp <= TW;
+    const int nmt = whole ? 4 : (npix_halo + 31) / 32;
     float4 X[16];
     unsigned long long vmask = 0ull;
     auto request = [&](int mt) {  // -> vmask of the M-tile; X = its 16 fragments (not requested for an all-outside M-tile)
         const int q = mt * 32 + j;
-        const int hr = q / HWP, hc = q - hr * HWP;
+        const int hr = whole ? (q >> 4) + 1 : q / HWP, hc = whole ? (q & 15) + 1 : q - hr * HWP;
         const int pr = t.ty0 - 1 + hr, pc = t.tx0 - 1 + hc;
-        const bool valid = (q < npix_halo) && (pr >= 0) && (pr < t.Hp) && (pc >= 0) && (pc < t.Wp);
+        const bool valid = (whole || q < npix_halo) && (pr >= 0) && (pr < t.Hp) && (pc >= 0) && (pc < t.Wp);
         vmask = __ballot(valid);
         if (vmask == 0ull) return;
         const float *xp = valid ? ximg + ((long)(t.py + pr * d) * a.W + (t.px + pc * d)) * C : ximg;
@@ -454,14 +459,23 @@ __global__ __launch_bounds__(256, 4) void k_bottleneck_o4(BnkArgs a)
         WL[(((s_ >> 2) * 64 + (k & 1) * 32 + co) << 2) + (s_ & 3)] = a.wp[e];
     }
     const float bs = a.ps[j], bt = a.pt[j], ba = a.pa[j];
+    if (whole) {  // the 52 ring pixels: top row, bottom row, then (left, right) of rows 1..8
+        for (int e = (int)threadIdx.x; e < 52 * F; e += 256) {
+            const int u = e >> 5, k = u - 2 * HWP;
+            const int q = u < HWP ? u : (u < 2 * HWP ? 9 * HWP + (u - HWP) : (1 + (k >> 1)) * HWP + ((k & 1) ? HWP - 1 : 0));
+            P[q * PSTR + (e & 31)] = 0.0f;
+        }
+    }
     __syncthreads();
-    for (int mt = mt0; mt < (npix_halo + 31) / 32; mt += 4) {
+    for (int mt = mt0; mt < nmt; mt += 4) {
         if (mt != mt0) request(mt);
         const unsigned long long vm64 = vmask;
+        // P row of the first pixel row (i = 0, h = 0) of the M-tile; rows of a whole-sub-image tile: see below
         if (vm64 == 0ull) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int qi = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                const int r0 = (i & 3) + 8 * (i >> 2), ri = r0 + 4 * h;
+                const int qi = whole ? (2 * mt + (i >> 3) + 1) * HWP + (r0 & 15) + 4 * h + 1 : mt * 32 + ri;
                 if (qi < O4_PROWS) P[qi * PSTR + kperm(j)] = 0.0f;
             }
             continue;
@@ -486,7 +500,9 @@ __global__ __launch_bounds__(256, 4) void k_bottleneck_o4(BnkArgs a)
             const int r0 = (i & 3) + 8 * (i >> 2), ri = r0 + 4 * h;
             const bool ok = (vmh >> r0) & 1u;
             const float v = ok ? prelu1(fmaf(acc[i], bs, bt), ba) : 0.0f;
-            if (mt * 32 + ri < O4_PROWS) P[(mt * 32 + ri) * PSTR + kperm(j)] = v;
+            // centre pixel mt * 32 + ri of a whole-sub-image tile = tile row 2 mt + (i >> 3), column (r0 & 15) + 4 h
+            const int qi = whole ? (2 * mt + (i >> 3) + 1) * HWP + (r0 & 15) + 4 * h + 1 : mt * 32 + ri;
+            if (qi < O4_PROWS) P[qi * PSTR + kperm(j)] = v;
         }
     }
     // this thread's 16 elements of the expansion kernel We[32][128] (L2 hits), requested before the barrier and written

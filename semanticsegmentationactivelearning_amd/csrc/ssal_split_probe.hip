@@ -15,6 +15,7 @@
 #include "ssal_prof.h"
 #include <map>
 #include <mutex>
+#include <utility>
 
 namespace ssal {
 
@@ -261,6 +262,184 @@ __global__ __launch_bounds__(256, 3) void k_bottleneck_split(BnkArgs a, const ui
     }
 }
 
+
+// ---- second form (bnk_split = 2): the block input is read ONCE.  8 x 16 tiles; wave w projects centre M-tile w -- the 32
+// pixels whose outputs it will produce -- and keeps their 64 input registers; the 52 ring pixels are two more M-tiles
+// (waves 0, 1, projected first).  The expansion runs as D[co][pixel] (lane = pixel), so that the kept registers, after one
+// v_permlane32_swap per register pair, ARE the residual of the lane's pixel in the accumulator's channel order, and the
+// output leaves as 16-byte stores of 4 consecutive channels.  Traffic: 1.41 x input + output instead of 1.33 x input +
+// residual + output.
+__global__ __launch_bounds__(256, 3) void k_bottleneck_split_r(BnkArgs a, const uint4 *wpk)
+{
+    constexpr int TW = 16, HWP = TW + 2, TH = 8, RING = 2 * HWP + 2 * TH;  // 52 ring pixels
+    __shared__ __attribute__((aligned(16))) float P[192 * SPS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int d = a.dil;
+    int b = blockIdx.x;
+    if (b >= a.ntiles) return;
+    const int tx = b % a.tiles_x; b /= a.tiles_x;
+    const int ty = b % a.tiles_y; b /= a.tiles_y;
+    const int px = b % d; b /= d;
+    const int py = b % d; b /= d;
+    const int n = b;
+    const int Hp = (a.H - py + d - 1) / d, Wp = (a.W - px + d - 1) / d;
+    const int ty0 = ty * TH, tx0 = tx * TW;
+    if (ty0 >= Hp || tx0 >= Wp) return;
+    const float *ximg = a.x + (long)n * a.H * a.W * C;
+    float *yimg = a.y + (long)n * a.H * a.W * C;
+    const rsrc_t wrs = make_rsrc(wpk, W_TOTAL * 16);
+    const float bs = a.ps[j], bt = a.pt[j], ba = a.pa[j];
+
+    // projection of one M-tile whose lane-j pixel is halo'd-tile position q (row q / 18, column q % 18; < 0: no pixel)
+    float4 X[16];
+    auto project = [&](int q) {
+        const int hr = q / HWP, hc = q - hr * HWP;
+        const int pr = ty0 - 1 + hr, pc = tx0 - 1 + hc;
+        const bool valid = (q >= 0) && (pr >= 0) && (pr < Hp) && (pc >= 0) && (pc < Wp);
+        const unsigned vm = (unsigned)__ballot(valid);
+        const float *xp = valid ? ximg + ((long)(py + pr * d) * a.W + (px + pc * d)) * C : ximg;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            X[2 * c] = *reinterpret_cast<const float4 *>(xp + 16 * c + 8 * h);
+            X[2 * c + 1] = *reinterpret_cast<const float4 *>(xp + 16 * c + 8 * h + 4);
+        }
+        f32x16 acc = {0};
+        Split3 wA = load_w(wrs, WP_OFF, lane), wB;  // packed kernel chunks one ahead (L2)
+#pragma unroll
+        for (int c = 0; c < 8; c += 2) {
+            wB = load_w(wrs, WP_OFF + (c + 1) * 192, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const float v[8] = {X[2 * c].x, X[2 * c].y, X[2 * c].z, X[2 * c].w, X[2 * c + 1].x, X[2 * c + 1].y,
+                                    X[2 * c + 1].z, X[2 * c + 1].w};
+                acc = mfma6(split_pack8(v), wA, acc);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 2 < 8) wA = load_w(wrs, WP_OFF + (c + 2) * 192, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const float v[8] = {X[2 * c + 2].x, X[2 * c + 2].y, X[2 * c + 2].z, X[2 * c + 2].w, X[2 * c + 3].x, X[2 * c + 3].y,
+                                    X[2 * c + 3].z, X[2 * c + 3].w};
+                acc = mfma6(split_pack8(v), wB, acc);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return std::make_pair(acc, vm);
+    };
+    auto q_ring = [&](int u) {
+        const int k = u - 2 * HWP;
+        return u < HWP ? u : (u < 2 * HWP ? (TH + 1) * HWP + (u - HWP) : (u < RING ? (1 + (k >> 1)) * HWP + ((k & 1) ? HWP - 1 : 0) : -1));
+    };
+    auto store_p = [&](const f32x16 &acc, unsigned vm, auto qrow) {  // rows = the M-tile's 32 pixels (registers), cols = co (lanes)
+        const unsigned vmh = vm >> (4 * h);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r0 = (i & 3) + 8 * (i >> 2);
+            const int q = qrow(r0 + 4 * h);
+            const bool ok = (vmh >> r0) & 1u;
+            if (q >= 0) P[q * SPS + j] = ok ? prelu1(fmaf(acc[i], bs, bt), ba) : 0.0f;
+        }
+    };
+    if (wave < 2) {  // ring M-tile `wave`: ring pixels 32 wave .. 32 wave + 31 (52 in all)
+        const auto r = project(q_ring(wave * 32 + j));
+        store_p(r.first, r.second, [&](int ri) { return q_ring(wave * 32 + ri); });
+    }
+    const int t = wave * 32 + j, tr_ = t >> 4, tc = t & 15;  // this lane's centre pixel: tile row tr_, column tc
+    {
+        const auto r = project((tr_ + 1) * HWP + tc + 1);
+        store_p(r.first, r.second, [&](int ri) { const int t2 = wave * 32 + ri; return ((t2 >> 4) + 1) * HWP + (t2 & 15) + 1; });
+    }
+    // X now holds the block input of the lane's centre pixel: channels 16 c + 8 h + 0..7.  One swap per register pair turns
+    // it into the residual in the expansion accumulator's order: X[2c].q = channel 16 c + 4 h + q, X[2c+1].q = 16 c + 8 + 4 h + q
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        swap32(X[2 * c].x, X[2 * c + 1].x);
+        swap32(X[2 * c].y, X[2 * c + 1].y);
+        swap32(X[2 * c].z, X[2 * c + 1].z);
+        swap32(X[2 * c].w, X[2 * c + 1].w);
+    }
+    __syncthreads();
+
+    // ---- phase B: conv D[co][pixel] -> BN + PReLU -> expansion D[co][pixel] -> BN + residual (registers) + PReLU
+    const rsrc_t esrs = make_rsrc(a.es, C * 4), etrs = make_rsrc(a.et, C * 4), rars = make_rsrc(a.ra, C * 4);
+    const rsrc_t srs = make_rsrc(a.cs, F * 4), trs = make_rsrc(a.ct, F * 4), ars = make_rsrc(a.ca, F * 4);
+    f32x16 acc = {0};
+    {
+        auto fetch = [&](int q, Split3 &w, float4 &p0, float4 &p1) {
+            const int tap = q >> 1, c2 = q & 1, kh = tap / 3, kw = tap - 3 * kh;
+            w = load_w(wrs, WC_OFF + q * 192, lane);
+            const float *pq = P + ((tr_ + kh) * HWP + (tc + kw)) * SPS + 8 * h + 16 * c2;
+            p0 = *reinterpret_cast<const float4 *>(pq);
+            p1 = *reinterpret_cast<const float4 *>(pq + 4);
+        };
+        Split3 wA, wB;
+        float4 a0, a1, b0, b1;
+        fetch(0, wA, a0, a1);
+#pragma unroll 1
+        for (int q = 0; q < 18; q += 2) {
+            fetch(q + 1, wB, b0, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                acc = mfma6(wA, split_pack8(v), acc);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 2 < 18) fetch(q + 2, wA, a0, a1);
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const float v[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                acc = mfma6(wB, split_pack8(v), acc);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float qv[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 s4 = bload4(srs, h * 16, g * 32), t4 = bload4(trs, h * 16, g * 32), a4 = bload4(ars, h * 16, g * 32);
+        qv[4 * g + 0] = prelu1(fmaf(acc[4 * g + 0], s4.x, t4.x), a4.x);
+        qv[4 * g + 1] = prelu1(fmaf(acc[4 * g + 1], s4.y, t4.y), a4.y);
+        qv[4 * g + 2] = prelu1(fmaf(acc[4 * g + 2], s4.z, t4.z), a4.z);
+        qv[4 * g + 3] = prelu1(fmaf(acc[4 * g + 3], s4.w, t4.w), a4.w);
+    }
+    Split3 qb[2];  // B operand of the flipped expansion: lane (pixel j, h) holds ci = 16 c + 8 h + 0..7
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) swap32(qv[8 * cc + q], qv[8 * cc + 4 + q]);
+        const float v[8] = {qv[8 * cc + 0], qv[8 * cc + 1], qv[8 * cc + 2], qv[8 * cc + 3],
+                            qv[8 * cc + 4], qv[8 * cc + 5], qv[8 * cc + 6], qv[8 * cc + 7]};
+        qb[cc] = split_pack8(v);
+    }
+    const int opr = ty0 + tr_, opc = tx0 + tc;
+    const bool ook = (opr < Hp) && (opc < Wp);
+    float *yp = yimg + (ook ? ((long)(py + opr * d) * a.W + (px + opc * d)) * C : 0) + 4 * h;
+    Split3 we0 = load_w(wrs, WE_OFF, lane), we1 = load_w(wrs, WE_OFF + 192, lane);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        f32x16 e = {0};
+        e = mfma6(we0, qb[0], e);  // D[co][pixel]: A = kernel (rows co), B = Q
+        e = mfma6(we1, qb[1], e);
+        if (nt < 3) {  // the next N-tile's kernel chunks travel while this one's epilogue runs
+            we0 = load_w(wrs, WE_OFF + (nt * 2 + 2) * 192, lane);
+            we1 = load_w(wrs, WE_OFF + (nt * 2 + 3) * 192, lane);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {  // reg 4g + q = channel 32 nt + 8 g + 4 h + q
+            const float4 s4 = bload4(esrs, h * 16, (nt * 32 + 8 * g) * 4), t4 = bload4(etrs, h * 16, (nt * 32 + 8 * g) * 4),
+                         a4 = bload4(rars, h * 16, (nt * 32 + 8 * g) * 4);
+            const float4 rx = X[2 * (2 * nt + (g >> 1)) + (g & 1)];
+            float4 o;
+            o.x = prelu1(fmaf(e[4 * g + 0], s4.x, t4.x) + rx.x, a4.x);
+            o.y = prelu1(fmaf(e[4 * g + 1], s4.y, t4.y) + rx.y, a4.y);
+            o.z = prelu1(fmaf(e[4 * g + 2], s4.z, t4.z) + rx.z, a4.z);
+            o.w = prelu1(fmaf(e[4 * g + 3], s4.w, t4.w) + rx.w, a4.w);
+            if (ook) *reinterpret_cast<float4 *>(yp + nt * 32 + 8 * g) = o;
+        }
+    }
+}
+
 // packed kernels, one buffer per layer (keyed by its projection-kernel pointer).  Every launch re-packs its layer's buffer
 // on its own stream: image-group chains that run the same layer side by side write identical bytes
 std::mutex g_split_mu;
@@ -282,17 +461,19 @@ hipError_t launch_bottleneck_split(const BnkArgs &a0, hipStream_t s)
         packed = slot;
     }
     a.TH = 8;
+    const bool form_r = knobs().bnk_split == 2;  // 8x16 tiles, block input read once
     const int Hp = (a.H + a.dil - 1) / a.dil, Wp = (a.W + a.dil - 1) / a.dil;
     a.tiles_y = (Hp + 7) / 8;
-    a.tiles_x = (Wp + 31) / 32;
+    a.tiles_x = form_r ? (Wp + 15) / 16 : (Wp + 31) / 32;
     const long grid = (long)a.N * a.dil * a.dil * a.tiles_y * a.tiles_x;
     if (grid <= 0 || grid > 0x3fffffffL) return hipErrorInvalidValue;
     a.ntiles = (int)grid;
     hipLaunchKernelGGL(k_split_pack, dim3(WP_CH + WC_CH + WE_CH), dim3(64), 0, s, a.wp, a.wc, a.we, packed);
     const double pix = (double)a.N * a.H * a.W;
-    ProfScope prof("k_bottleneck_split (bf16x3, measurement only)", 2.0 * pix * (C * F + 9.0 * F * F + F * C),
-                   4.0 * (2.0 * pix * C + C * F * 2.0 + 9.0 * F * F), s);
-    hipLaunchKernelGGL(k_bottleneck_split, dim3((unsigned)grid), dim3(256), 0, s, a, (const uint4 *)packed);
+    ProfScope prof(form_r ? "k_bottleneck_split_r (bf16x3, input read once; measurement only)" : "k_bottleneck_split (bf16x3, measurement only)",
+                   2.0 * pix * (C * F + 9.0 * F * F + F * C), 4.0 * (2.0 * pix * C + C * F * 2.0 + 9.0 * F * F), s);
+    if (form_r) hipLaunchKernelGGL(k_bottleneck_split_r, dim3((unsigned)grid), dim3(256), 0, s, a, (const uint4 *)packed);
+    else hipLaunchKernelGGL(k_bottleneck_split, dim3((unsigned)grid), dim3(256), 0, s, a, (const uint4 *)packed);
     return hipGetLastError();
 }
 

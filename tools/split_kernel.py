@@ -38,25 +38,41 @@ def timed(layer, x, reps=10):
 
 
 x = torch.from_numpy(np.random.default_rng(5).normal(size=(8, 128, 256, 128)).astype(np.float32)).cuda()
+FORMS = {1: "split   (8x32 tiles, traffic of the product kernel)", 2: "split_r (8x16 tiles, block input read once)"}
 for name in ("Bottleneck2_1", "Bottleneck2_2", "Bottleneck2_4", "Bottleneck2_6", "Bottleneck2_8"):
     layer = getattr(net, name)
     _lib.set_knob("bnk_split", 0)
     ref, t0 = timed(layer, x)
-    _lib.set_knob("bnk_split", 1)
-    got, t1 = timed(layer, x)
+    print("%-14s exact %s" % (name, {k.replace("k_", ""): round(v, 1) for k, v in t0.items()}))
+    for form, label in FORMS.items():
+        _lib.set_knob("bnk_split", form)
+        got, t1 = timed(layer, x)
+        _lib.set_knob("bnk_split", 0)
+        d = (got.double() - ref.double())
+        print("    %-52s %6.1f us | max |d| %.3e rms %.3e (|y| max %.2f rms %.3f)" % (
+            label, list(t1.values())[0], d.abs().max().item(), d.pow(2).mean().sqrt().item(), ref.abs().max().item(),
+            ref.pow(2).mean().sqrt().item()))
+
+# ragged shape through both forms (border tiles, partial sub-images)
+xr = torch.from_numpy(np.random.default_rng(6).normal(size=(2, 72, 136, 128)).astype(np.float32)).cuda()
+for name in ("Bottleneck2_1", "Bottleneck2_4"):
+    layer = getattr(net, name)
     _lib.set_knob("bnk_split", 0)
-    d = (got.double() - ref.double())
-    print("%-14s exact %s | split %s | max |d| %.3e rms %.3e (|y| max %.2f rms %.3f)" % (
-        name, {k.replace("k_", ""): round(v, 1) for k, v in t0.items()}, {k.split(" ")[0].replace("k_", ""): round(v, 1) for k, v in t1.items()},
-        d.abs().max().item(), d.pow(2).mean().sqrt().item(), ref.abs().max().item(), ref.pow(2).mean().sqrt().item()))
+    ref = layer(xr, training=False).clone()
+    for form in FORMS:
+        _lib.set_knob("bnk_split", form)
+        got = layer(xr, training=False)
+        _lib.set_knob("bnk_split", 0)
+        print("ragged 2x72x136 %-14s form %d: max |d| %.3e" % (name, form, (got.double() - ref.double()).abs().max().item()))
 
 f = syn.synth_frames_device(7, 1, 256, 512, 3)
 _lib.set_knob("bnk_split", 0)
 ref = net(f, training=False).clone()
-_lib.set_knob("bnk_split", 1)
-got = net(f, training=False).clone()
-_lib.set_knob("bnk_split", 0)
-d = got.double() - ref.double()
-print("whole forward 256x512, 12 regular 128-channel layers split: logits max |d| %.3e rms %.3e (|logit| max %.1f); labels changed: %d of %d"
-      % (d.abs().max().item(), d.pow(2).mean().sqrt().item(), ref.abs().max().item(),
-         int((got.argmax(-1) != ref.argmax(-1)).sum().item()), ref.shape[1] * ref.shape[2]))
+for form, label in FORMS.items():
+    _lib.set_knob("bnk_split", form)
+    got = net(f, training=False).clone()
+    _lib.set_knob("bnk_split", 0)
+    d = got.double() - ref.double()
+    print("whole forward 256x512, 12 regular 128-channel layers on %s: logits max |d| %.3e rms %.3e (|logit| max %.1f); labels changed: %d of %d"
+          % (label.split("(")[0].strip(), d.abs().max().item(), d.pow(2).mean().sqrt().item(), ref.abs().max().item(),
+             int((got.argmax(-1) != ref.argmax(-1)).sum().item()), ref.shape[1] * ref.shape[2]))

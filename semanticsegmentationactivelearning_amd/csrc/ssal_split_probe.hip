@@ -111,11 +111,13 @@ __device__ __forceinline__ Split3 load_w(const rsrc_t &rs, int unit_off, int lan
     return s;
 }
 
-// 8 x 32 tiles of one dilation phase sub-image, exactly as k_bottleneck_mfma<32> (ssal_bottleneck_mfma.hip)
-__global__ __launch_bounds__(256, 3) void k_bottleneck_split(BnkArgs a, const uint4 *wpk)
+// 8 x 32 tiles of one dilation phase sub-image, exactly as k_bottleneck_mfma<32> (ssal_bottleneck_mfma.hip); TW = 16 (knob
+// bnk_split = 3): 8 x 16 tiles at FOUR workgroups per CU (121 VGPRs, 27.6 KB of LDS)
+template <int TW>
+__global__ __launch_bounds__(256, TW == 16 ? 4 : 3) void k_bottleneck_split(BnkArgs a, const uint4 *wpk)
 {
-    constexpr int TW = 32, HWP = TW + 2, TH = 8;
-    __shared__ __attribute__((aligned(16))) float P[SP_ROWS * SPS];
+    constexpr int HWP = TW + 2, TH = 8;
+    __shared__ __attribute__((aligned(16))) float P[(TW == 16 ? 192 : SP_ROWS) * SPS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int d = a.dil;
@@ -462,18 +464,21 @@ hipError_t launch_bottleneck_split(const BnkArgs &a0, hipStream_t s)
     }
     a.TH = 8;
     const bool form_r = knobs().bnk_split == 2;  // 8x16 tiles, block input read once
+    const bool form_16 = knobs().bnk_split == 3;  // the first form on 8x16 tiles, four workgroups per CU
     const int Hp = (a.H + a.dil - 1) / a.dil, Wp = (a.W + a.dil - 1) / a.dil;
     a.tiles_y = (Hp + 7) / 8;
-    a.tiles_x = form_r ? (Wp + 15) / 16 : (Wp + 31) / 32;
+    a.tiles_x = (form_r || form_16) ? (Wp + 15) / 16 : (Wp + 31) / 32;
     const long grid = (long)a.N * a.dil * a.dil * a.tiles_y * a.tiles_x;
     if (grid <= 0 || grid > 0x3fffffffL) return hipErrorInvalidValue;
     a.ntiles = (int)grid;
     hipLaunchKernelGGL(k_split_pack, dim3(WP_CH + WC_CH + WE_CH), dim3(64), 0, s, a.wp, a.wc, a.we, packed);
     const double pix = (double)a.N * a.H * a.W;
-    ProfScope prof(form_r ? "k_bottleneck_split_r (bf16x3, input read once; measurement only)" : "k_bottleneck_split (bf16x3, measurement only)",
+    ProfScope prof(form_r ? "k_bottleneck_split_r (bf16x3, input read once; measurement only)"
+                          : form_16 ? "k_bottleneck_split<16> (bf16x3, 4 workgroups per CU; measurement only)" : "k_bottleneck_split (bf16x3, measurement only)",
                    2.0 * pix * (C * F + 9.0 * F * F + F * C), 4.0 * (2.0 * pix * C + C * F * 2.0 + 9.0 * F * F), s);
     if (form_r) hipLaunchKernelGGL(k_bottleneck_split_r, dim3((unsigned)grid), dim3(256), 0, s, a, (const uint4 *)packed);
-    else hipLaunchKernelGGL(k_bottleneck_split, dim3((unsigned)grid), dim3(256), 0, s, a, (const uint4 *)packed);
+    else if (form_16) hipLaunchKernelGGL(k_bottleneck_split<16>, dim3((unsigned)grid), dim3(256), 0, s, a, (const uint4 *)packed);
+    else hipLaunchKernelGGL(k_bottleneck_split<32>, dim3((unsigned)grid), dim3(256), 0, s, a, (const uint4 *)packed);
     return hipGetLastError();
 }
 

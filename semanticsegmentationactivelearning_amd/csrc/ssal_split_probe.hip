@@ -24,6 +24,9 @@ constexpr int F = 32, C = 128;
 constexpr int SPS = 36;        // LDS pixel stride of P in floats: 144 B rows keep the 16-byte reads aligned and conflict-free
 constexpr int SP_ROWS = 352;   // (8+2) x (32+2) = 340 halo'd pixels, rounded up to whole M-tiles
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#ifndef SSAL_SPLIT16_OCC
+#define SSAL_SPLIT16_OCC 4
+#endif
 
 struct Split3 {
     uint4 t1, t2, t3;  // 8 values each: the leading bf16, the bf16 of the remainder, the bf16 of what remains after that
@@ -114,7 +117,7 @@ __device__ __forceinline__ Split3 load_w(const rsrc_t &rs, int unit_off, int lan
 // 8 x 32 tiles of one dilation phase sub-image, exactly as k_bottleneck_mfma<32> (ssal_bottleneck_mfma.hip); TW = 16 (knob
 // bnk_split = 3): 8 x 16 tiles at FOUR workgroups per CU (121 VGPRs, 27.6 KB of LDS)
 template <int TW>
-__global__ __launch_bounds__(256, TW == 16 ? 4 : 3) void k_bottleneck_split(BnkArgs a, const uint4 *wpk)
+__global__ __launch_bounds__(256, TW == 16 ? SSAL_SPLIT16_OCC : 3) void k_bottleneck_split(BnkArgs a, const uint4 *wpk)
 {
     constexpr int HWP = TW + 2, TH = 8;
     __shared__ __attribute__((aligned(16))) float P[(TW == 16 ? 192 : SP_ROWS) * SPS];

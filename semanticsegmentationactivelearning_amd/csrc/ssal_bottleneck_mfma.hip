@@ -60,7 +60,7 @@ __device__ __forceinline__ void proj_to_lds(const Args &a, const float *ximg, fl
     // The first KEEP k-pair steps stay in registers; the tail is re-fetched (L1) per M-tile into the
     // registers the first activation fragments have just vacated -- this keeps the kernel at 168 VGPRs
     // = 3 workgroups per CU.
-    constexpr int KEEP = 40, UK = KEEP / 4;  // UK = float4 fragments covered by the resident part
+    constexpr int KEEP = 36, UK = KEEP / 4;  // UK = float4 fragments covered by the resident part (24 .. 48 swept in round 4: profiles/r04_ab_keep_sweep.txt)
     float wpr[KEEP];
     const rsrc_t wrs = make_rsrc(a.wp, C * F * 4);
     const unsigned wlo = (unsigned)(h * 32 + j) * 4u;

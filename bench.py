@@ -255,7 +255,8 @@ def kernel_roofline(name, d, reps, pmc):
     traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
     # "mfma" is the schema's name for the compute roof; the fp32 VECTOR peak equals the fp32 MFMA peak on this part
     # (157.3 TFLOP/s), and these two kernels run their FLOPs on packed VALU FMAs, not on the matrix cores
-    pipe = None if bound != "mfma" else ("valu (v_pk_fma_f32)" if name.startswith(("k_final_score", "k_upscore", "k_conv_first")) else "mfma")
+    pipe = None if bound != "mfma" else ("valu (v_pk_fma_f32)" if name.startswith(("k_final_score", "k_upscore", "k_conv_first"))
+                                         else "valu (v_pk_fma_f32) conv 1 + mfma conv 2" if name.startswith("k_front2") else "mfma")
     return {"bound": bound, "pipe": pipe, "achieved": achieved, "peak": peak, "unit": unit,
             "frac": (achieved / peak) if achieved is not None else None, "traffic": traffic,
             "traffic_over_algorithmic": (traffic / (d["bytes"] / n)) if (traffic and d["bytes"] > 0) else None,

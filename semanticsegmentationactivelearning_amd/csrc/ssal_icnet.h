@@ -43,6 +43,14 @@ hipError_t launch_igemm(const float *x, int N, int H, int W, int Cin, const floa
 hipError_t launch_conv_first(const void *x, bool x_is_u8, int N, int H, int W, int Cin, int sub, const float *w,
                              const float *scale, const float *shift, float *y, hipStream_t s);
 
+// the first TWO convolutions of a branch in one launch (ssal_icnet_front.hip): launch_conv_first(x, ..., sub, w1, s1, t1)
+// followed by the 3x3 / stride `stride2` (1 or 2) / SAME convolution 32 -> 32 + BN + ReLU whose kernel is w2_igemm
+// (igemm_relayout layout); y = [N, H/sub/2/stride2, W/sub/2/stride2, 32].  Bit-identical to the two launches.
+bool front2_supported(int H, int W, int Cin, int sub, int stride2);
+hipError_t launch_front2(const void *x, bool x_is_u8, int N, int H, int W, int Cin, int sub, const float *w1,
+                         const float *s1, const float *t1, const float *w2_igemm, const float *s2, const float *t2,
+                         int stride2, float *y, hipStream_t s);
+
 // tf.nn.max_pool(3x3, stride 2, SAME); C % 4 == 0
 hipError_t launch_maxpool3x3_s2(const float *x, int N, int H, int W, int C, float *y, hipStream_t s);
 

@@ -243,11 +243,18 @@ hipError_t run_trunk(const ssal_icnet *net, std::vector<Grp> &grp, bool x_is_u8,
         if (e_ != hipSuccess) return e_;               \
     }
     // ---- medium-resolution branch / shared stem (section 1) ----
-    {
+    // fused score path: the first two convolutions of a branch in one launch (k_front2), the first one's output never
+    // reaches HBM (and is no endpoint of such a call)
+    const int front = fused && ssal::mfma_family() ? ssal::knobs().ic_front : 0;
+    if ((front & 2) && front2_supported(h, w, net->c_in, 2, 1)) {
+        const ConvDev &c = net->convs.at("conv1_1_3x3_s2"), &c2 = net->convs.at("conv1_2_3x3");
+        EACH(launch_front2(q.x, x_is_u8, q.n, h, w, net->c_in, 2, c.w, c.scale, c.shift, c2.w, c2.scale, c2.shift, 1,
+                           q.A("conv1_2_3x3"), q.s));
+    } else {
         const ConvDev &c = net->convs.at("conv1_1_3x3_s2");
         EACH(launch_conv_first(q.x, x_is_u8, q.n, h, w, net->c_in, 2, c.w, c.scale, c.shift, q.A("conv1_1_3x3_s2"), q.s));
+        EACH(run_conv(net, "conv1_2_3x3", q.A("conv1_1_3x3_s2"), q.n, h / 4, w / 4, nullptr, true, false, q.A("conv1_2_3x3"), q.s));
     }
-    EACH(run_conv(net, "conv1_2_3x3", q.A("conv1_1_3x3_s2"), q.n, h / 4, w / 4, nullptr, true, false, q.A("conv1_2_3x3"), q.s));
     EACH(run_conv(net, "conv1_3_3x3", q.A("conv1_2_3x3"), q.n, h / 4, w / 4, nullptr, true, false, q.A("conv1_3_3x3"), q.s));
     EACH(launch_maxpool3x3_s2(q.A("conv1_3_3x3"), q.n, h / 4, w / 4, 64, q.A("pool1_3x3_s2"), q.s));
     std::string cur = "pool1_3x3_s2";
@@ -292,11 +299,15 @@ hipError_t run_trunk(const ssal_icnet *net, std::vector<Grp> &grp, bool x_is_u8,
     EACH(launch_ppm(q.A(cur), q.n, ch, cw, 1024, q.W.pooled, q.A("conv5_3_sum"), q.s));
     EACH(run_conv(net, "conv5_4_k1", q.A("conv5_3_sum"), q.n, ch, cw, nullptr, true, false, q.A("conv5_4_k1"), q.s));
     // ---- high-resolution branch (section 3) ----
-    {
+    if ((front & 1) && front2_supported(h, w, net->c_in, 1, 2)) {
+        const ConvDev &c = net->convs.at("conv1_sub1"), &c2 = net->convs.at("conv2_sub1");
+        EACH(launch_front2(q.x, x_is_u8, q.n, h, w, net->c_in, 1, c.w, c.scale, c.shift, c2.w, c2.scale, c2.shift, 2,
+                           q.A("conv2_sub1"), q.s));
+    } else {
         const ConvDev &c = net->convs.at("conv1_sub1");
         EACH(launch_conv_first(q.x, x_is_u8, q.n, h, w, net->c_in, 1, c.w, c.scale, c.shift, q.A("conv1_sub1"), q.s));
+        EACH(run_conv(net, "conv2_sub1", q.A("conv1_sub1"), q.n, h / 2, w / 2, nullptr, true, false, q.A("conv2_sub1"), q.s));
     }
-    EACH(run_conv(net, "conv2_sub1", q.A("conv1_sub1"), q.n, h / 2, w / 2, nullptr, true, false, q.A("conv2_sub1"), q.s));
     EACH(run_conv(net, "conv3_sub1", q.A("conv2_sub1"), q.n, h / 4, w / 4, nullptr, true, false, q.A("conv3_sub1"), q.s));
     // ---- cascade feature fusion (section 4): the 2x interpolations are evaluated inside the dilated convs ----
     EACH(run_conv(net, "conv3_1_sub2_proj", q.A("conv3_1"), q.n, h / 16, w / 16, nullptr, false, false,

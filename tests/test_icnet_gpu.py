@@ -488,3 +488,34 @@ def test_interleaved_models_batches_and_shapes_match_the_single_stream_unfused_p
     for i, (a, b, c) in enumerate(zip(got, want, again)):
         assert np.array_equal(a, b), "call %d of the plan differs from the single-stream, unfused result" % i
         assert np.array_equal(a, c), "call %d of the plan is not reproducible" % i
+
+
+@pytest.mark.parametrize("n,h,w,u8", [(3, 64, 96, False), (1, 32, 32, False), (2, 160, 224, True), (5, 96, 64, False)])
+def test_fused_branch_fronts_are_bit_identical(icnet19, n, h, w, u8):
+    """knob ic_front: conv1_sub1 + conv2_sub1 (bit 0) and conv1_1_3x3_s2 + conv1_2_3x3 (bit 1) as ONE launch each
+    (k_front2, csrc/ssal_icnet_front.hip; the first convolution's output never reaches HBM).  The second convolution's
+    output must equal the per-layer path's bit for bit (ragged tiles, image borders, uint8 frames), and so must scores
+    and labels, with one and with two image chains."""
+    net, _ = icnet19
+    x = syn.synth_frames_device(11, n, h, w, 3)
+    if u8:
+        x = (x * 255.0).round().clamp(0, 255).to(torch.uint8)
+    shipped = _lib.get_knobs()["ic_front"]
+    try:
+        _lib.set_knob("img_groups", 1)
+        _lib.set_knob("ic_front", 0)
+        s0, e0 = net.score(x, "margin", return_label=True, return_confidence=True)
+        want = {k: net.endpoint(k).clone() for k in ("conv2_sub1", "conv1_2_3x3")}
+        for front in (1, 2, 3):
+            _lib.set_knob("ic_front", front)
+            for groups in (1, 2):
+                _lib.set_knob("img_groups", groups)
+                s, e = net.score(x, "margin", return_label=True, return_confidence=True)
+                assert torch.equal(s, s0) and torch.equal(e["label"], e0["label"]) and torch.equal(e["confidence"], e0["confidence"]), \
+                    "ic_front=%d img_groups=%d changes the result" % (front, groups)
+                if groups == 1:
+                    for k, t in want.items():
+                        assert torch.equal(net.endpoint(k), t), "ic_front=%d: %s differs" % (front, k)
+    finally:
+        _lib.set_knob("img_groups", 2)
+        _lib.set_knob("ic_front", shipped)

@@ -124,6 +124,12 @@ __device__ __forceinline__ void front_conv1(const float (*v)[9][CIN], const int 
                     for (int p = 0; p < 4; ++p)
                         acc[j][p] = __builtin_elementwise_fma(a2, f32x2{wc[ci * 8 + 2 * p], wc[ci * 8 + 2 * p + 1]}, acc[j][p]);
                 }
+            // pin this tap's FMAs HERE: the builtins around them order only side effects, and instruction selection is free
+            // to line all 27 scalar loads up first (into spilled SGPRs) and the FMAs behind them
+#pragma unroll
+            for (int j = 0; j < NP; ++j)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) asm volatile("" : "+v"(acc[j][p]));
             __builtin_amdgcn_sched_barrier(0);
         }
         // folded batch-norm + ReLU -> the window (exact zeros outside conv 1's output: conv 2's SAME padding)

@@ -19,8 +19,9 @@
 //                   ahead, right behind the barrier that opens phase 2, and land under its MFMAs.
 //                   Stride 1: 180 pixels = 3 passes; wave w evaluates channel group w of all three.
 //   phase 2 (MFMA)  k_conv3x3_c32's K loop on the window; the 9 x 32 x 32 kernel slice is NOT staged in LDS (41 KB: the
-//                   stride-2 window's 79 KB would then leave room for one workgroup per CU) -- its fragments come from
-//                   L1 / L2 one tap ahead, as in ENet's fused bottleneck.  For stride 2 the window's columns are stored
+//                   stride-2 window's 79 KB would then leave room for one workgroup per CU) -- the fragments of the first
+//                   four taps are resident in registers, the others come from L1 / L2 one tap ahead, as in ENet's fused
+//                   bottleneck.  For stride 2 the window's columns are stored
 //                   de-interleaved (even columns, then odd columns of a row), so that the 16 pixels a quarter-wave
 //                   reads for one tap are neighbours in LDS (conflict-free ds_read_b128).
 //   Two workgroups per CU: one's MFMA phase runs under the other's VALU phase.
@@ -232,6 +233,18 @@ __global__ __launch_bounds__(256, 2) void k_front2(FrontArgs a, const float *__r
         }
     };
     load_image(sp, true);
+    // conv 2's kernel fragments: those of the first RES taps stay in registers for the life of the (persistent) workgroup
+    // (64 of the 73 registers the 256-register budget of two workgroups per CU leaves), the others come from L1 / L2 one
+    // tap ahead.  All 36 resident would be 144 registers -- what the first version of this kernel did, at the price of
+    // having no room to request the image one tile ahead.  0 -> 4 resident taps: 284 -> 274 us.
+    constexpr int RES = 4;
+    auto load_b = [&](int tap, float4 (&b)[4]) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b[g] = bload4(wrs, blo, (unsigned)(tap * 1024 + 8 * g) * 4u);
+    };
+    float4 bres[RES > 0 ? RES : 1][4];
+#pragma unroll
+    for (int tp = 0; tp < RES; ++tp) load_b(tp, bres[tp]);
 
     for (; sp < nsp; sp += step) {
         const Tile t = decode(sp);
@@ -262,21 +275,17 @@ __global__ __launch_bounds__(256, 2) void k_front2(FrontArgs a, const float *__r
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc2[i] = 0.0f;
         float4 af[2], bq[2][4];
-        auto load_b = [&](int tap, float4 (&b)[4]) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) b[g] = bload4(wrs, blo, (unsigned)(tap * 1024 + 8 * g) * 4u);
-        };
-        load_b(0, bq[0]);
+        load_b(RES, bq[RES & 1]);
         af[0] = *reinterpret_cast<const float4 *>(Ab);
 #pragma unroll
         for (int s = 0; s < 36; ++s) {  // s = tap * 4 + group
             const int c = s & 1, nx = c ^ 1, tap = s >> 2, g = s & 3;
-            if (g == 0 && tap + 1 < 9) load_b(tap + 1, bq[(tap + 1) & 1]);
+            if (g == 0 && tap + 1 > RES && tap + 1 < 9) load_b(tap + 1, bq[(tap + 1) & 1]);
             if (s + 1 < 36) {
                 const int t1_ = (s + 1) >> 2, g1 = (s + 1) & 3;
                 af[nx] = *reinterpret_cast<const float4 *>(Ab + tap_slot(t1_ / 3, t1_ % 3) * LDK + 8 * g1);
             }
-            const float4 b = bq[tap & 1][g];
+            const float4 b = tap < RES ? bres[tap][g] : bq[tap & 1][g];
             acc2 = mfma32(af[c].x, b.x, acc2);
             acc2 = mfma32(af[c].y, b.y, acc2);
             acc2 = mfma32(af[c].z, b.z, acc2);

@@ -915,7 +915,7 @@ def test_spatial_dropout_op():
 
 
 @pytest.mark.parametrize("classes,c_in,n,h,w", [(19, 3, 3, 8, 8), (19, 3, 2, 24, 40), (6, 4, 1, 136, 72), (2, 1, 5, 16, 8),
-                                                (32, 3, 2, 40, 24), (7, 3, 1, 264, 520)])
+                                                (32, 3, 2, 40, 24), (7, 3, 1, 264, 520), (13, 3, 2, 56, 24), (20, 3, 1, 40, 72)])
 def test_fused_ends_equal_the_per_layer_launches(classes, c_in, n, h, w):
     """round 3: the ranking pass (score only) runs Initial + Bottleneck1_0 as one launch (k_initial_down16) and evaluates
     Bottleneck5_1 inside the Final + score kernel; a score call that also returns labels takes the per-layer launches for

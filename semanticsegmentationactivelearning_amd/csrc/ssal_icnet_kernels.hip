@@ -47,7 +47,11 @@ constexpr unsigned IG_OOB = 0xFFFFFFFFu;  // a byte offset no tensor reaches: ra
 // 32-bit per-lane byte offset.  A pixel row's offset is computed ONCE; per K-chunk it only receives a wave-uniform
 // increment (tap displacement + channel chunk), and taps that fall into the SAME zero padding (or rows past the end of
 // the tensor) use the out-of-range offset, which the hardware answers with zeros -- no branches, no 64-bit math.
-template <int NT, bool UP2>
+// UP2: 0 = plain; 1 = the conv runs on resize_bilinear(x, 2x), four neighbours fetched per A row (any shape); 2 = the same
+// for stride 1, even dilation / padding and Wo % 4 == 0 (ICNet's conv_sub4 / conv_sub2): a thread owns four ADJACENT output
+// pixels of one image row, whose taps interpolate from 3 source columns x 2 source rows -- 6 loads per chunk instead of 16,
+// same four source values and the same lerp formula per pixel, i.e. the same bits.
+template <int NT, int UP2>
 __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
 {
     constexpr int BM = IG_BM, BN = 32 * NT, LDK = IG_LDK;
@@ -75,18 +79,19 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
     const int n0 = tn * BN;
     const int M = (int)a.M;
 
-    const int Hs = UP2 ? a.H >> 1 : a.H, Ws = UP2 ? a.W >> 1 : a.W;  // dims of the tensor in memory
+    const int Hs = UP2 ? a.H >> 1 : a.H, Ws = UP2 ? a.W >> 1 : a.W;  // dims of the tensor in memory (UP2: int, 0 / 1 / 2)
     const rsrc_t xrs = make_rsrc(a.x, (unsigned)((long)a.N * Hs * Ws * a.Cin * 4));
     const rsrc_t wrs = make_rsrc(a.wt, (unsigned)((long)a.KH * a.KW * a.Cin * a.CoutP * 4));
 
-    // ---- per-thread A rows: (tid >> 3) + 32 i, channel quad tid & 7 ------------------------------
+    // ---- per-thread A rows: (tid >> 3) + 32 i (UP2 == 2: 4 (tid >> 3) + i), channel quad tid & 7 ----
     const int col4 = tid & 7;
+    auto arow = [&](int i) { return UP2 == 2 ? 4 * (tid >> 3) + i : (tid >> 3) + 32 * i; };
     int iyb[4], ixb[4];
     unsigned nbase[4];  // byte offset of the row's image
     bool mv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int m = m0 + (tid >> 3) + 32 * i;
+        const int m = m0 + arow(i);
         mv[i] = m < M;
         const unsigned mm = mv[i] ? (unsigned)m : 0u;
         const unsigned t = mm / (unsigned)a.Wo;
@@ -107,20 +112,42 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
     // within a tap a chunk only adds the wave-uniform 128 * ld_cc, which rides in the instruction's scalar offset
     // (excluded from the range check, so an out-of-range row offset stays out of range).  A 1x1 convolution computes its
     // offsets once; a 3x3 one on 256 channels once per 8 chunks.
-    constexpr int NOFF = UP2 ? 16 : 4;
+    constexpr int NOFF = UP2 == 1 ? 16 : UP2 == 2 ? 6 : 4;
     unsigned aoff[NOFF];
-    float4 rq[NOFF];  // the loaded quads of the next chunk (UP2: the four neighbours tl, tr, bl, br of each row)
+    float4 rq[NOFF];  // the loaded quads of the next chunk (UP2 = 1: the four neighbours tl, tr, bl, br of each row;
+                      // UP2 = 2: source rows y0, y1 x source columns A, B, C shared by the thread's four pixels)
     float lyv[4], lxv[4];  // UP2: the two interpolation weights of each row (0 or 0.5)
+    bool pok[2] = {false, false};  // UP2 = 2: pixel pairs (0, 1) / (2, 3) inside the image for the current tap
     int ld_cc = 0, ld_kh = 0, ld_kw = 0;
     unsigned ld_wofs = (unsigned)n0 * 128u;  // wave-uniform byte offset of the kernel rows of the next chunk
     auto tap_offsets = [&]() {
+        if (UP2 == 2) {
+            // the four pixels sit in one image row at ix0 .. ix0 + 3 with ix0 even (launcher): pairs (ix0, ix0 + 1) and
+            // (ix0 + 2, ix0 + 3) read source columns (A, B) and (B, C), A = ix0 >> 1, B / C its right neighbours clamped
+            // as the per-pixel rule x1 = min(x0 + 1, Ws - 1) clamps them; a pair is inside the image or outside as a whole
+            const int iy = iyb[0] + ld_kh * a.dil, ix0 = ixb[0] + ld_kw * a.dil;
+            const bool rowok = mv[0] && iy >= 0 && iy < a.H;
+            pok[0] = rowok && ix0 >= 0 && ix0 < a.W;
+            pok[1] = rowok && ix0 + 2 >= 0 && ix0 + 2 < a.W;
+            const int y0 = iy >> 1, y1 = min(y0 + 1, Hs - 1);
+            const int xa = ix0 >> 1, xb = min(xa + 1, Ws - 1), xc = min(xa + 2, Ws - 1);
+            lyv[0] = (iy & 1) ? 0.5f : 0.0f;
+            const unsigned b0 = nbase[0] + (unsigned)y0 * rowb, b1 = nbase[0] + (unsigned)y1 * rowb;
+            aoff[0] = pok[0] ? b0 + (unsigned)xa * pixb : IG_OOB;
+            aoff[1] = (pok[0] || pok[1]) ? b0 + (unsigned)xb * pixb : IG_OOB;
+            aoff[2] = pok[1] ? b0 + (unsigned)xc * pixb : IG_OOB;
+            aoff[3] = pok[0] ? b1 + (unsigned)xa * pixb : IG_OOB;
+            aoff[4] = (pok[0] || pok[1]) ? b1 + (unsigned)xb * pixb : IG_OOB;
+            aoff[5] = pok[1] ? b1 + (unsigned)xc * pixb : IG_OOB;
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int iy = iyb[i] + ld_kh * a.dil, ix = ixb[i] + ld_kw * a.dil;
             const bool ok = mv[i] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            if (!UP2) {
+            if (UP2 == 0) {
                 aoff[i] = ok ? nbase[i] + (unsigned)iy * rowb + (unsigned)ix * pixb : IG_OOB;
-            } else {
+            } else if (UP2 == 1) {
                 // tf.image.resize_bilinear(src, 2x), legacy mapping src = dst * 0.5 (ICNET_SPEC "bilinear resize");
                 // out-of-image taps read four zeros and interpolate to an exact zero
                 const int y0 = iy >> 1, x0 = ix >> 1;
@@ -157,11 +184,13 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
         float4 ra[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (!UP2) {
+            if (UP2 == 0) {
                 ra[i] = rq[i];
             } else {  // the interpolation happens here, i.e. after the loads have had the matrix section to land
-                const float4 tl = rq[4 * i], tr = rq[4 * i + 1], bl = rq[4 * i + 2], br = rq[4 * i + 3];
-                const float lx = lxv[i], ly = lyv[i];
+                const int pr_ = i >> 1;  // UP2 == 2: pixel pair -> source columns (A, B) or (B, C)
+                const float4 tl = UP2 == 2 ? rq[pr_] : rq[4 * i], tr = UP2 == 2 ? rq[pr_ + 1] : rq[4 * i + 1];
+                const float4 bl = UP2 == 2 ? rq[3 + pr_] : rq[4 * i + 2], br = UP2 == 2 ? rq[4 + pr_] : rq[4 * i + 3];
+                const float lx = UP2 == 2 ? ((i & 1) ? 0.5f : 0.0f) : lxv[i], ly = UP2 == 2 ? lyv[0] : lyv[i];
                 auto lerp2 = [&](float ctl, float ctr, float cbl, float cbr) {
                     const float top = ctl + (ctr - ctl) * lx;
                     const float bot = cbl + (cbr - cbl) * lx;
@@ -169,6 +198,8 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
                 };
                 ra[i] = make_float4(lerp2(tl.x, tr.x, bl.x, br.x), lerp2(tl.y, tr.y, bl.y, br.y),
                                     lerp2(tl.z, tr.z, bl.z, br.z), lerp2(tl.w, tr.w, bl.w, br.w));
+                // a pair outside the image is an exact zero (the per-pixel form reads four zeros there); column B is shared
+                if (UP2 == 2 && !pok[pr_]) ra[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
         }
 #pragma unroll
@@ -176,11 +207,11 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
             if (A_PERMUTED) {
                 // channels 4*col4 .. +3 = (k, k+1, k+2, k+3) with k = 0 or 4 (mod 8): k and k+2 are neighbours in
                 // the permuted row, so are k+1 and k+3
-                float *ap = As + ((tid >> 3) + 32 * i) * LDK + 8 * (col4 >> 1) + 2 * (col4 & 1);
+                float *ap = As + arow(i) * LDK + 8 * (col4 >> 1) + 2 * (col4 & 1);
                 *reinterpret_cast<float2 *>(ap) = make_float2(ra[i].x, ra[i].z);
                 *reinterpret_cast<float2 *>(ap + 4) = make_float2(ra[i].y, ra[i].w);
             } else {
-                *reinterpret_cast<float4 *>(As + ((tid >> 3) + 32 * i) * LDK + 4 * col4) = ra[i];
+                *reinterpret_cast<float4 *>(As + arow(i) * LDK + 4 * col4) = ra[i];
             }
         }
     };
@@ -689,9 +720,12 @@ hipError_t launch_igemm(const float *x, int N, int H, int W, int Cin, const floa
     // one profile row per kernel SYMBOL (rocprofv3 lists k_igemm<NT, false> and k_igemm<NT, true> separately)
     ProfScope prof(up2 ? (NT == 4 ? "k_igemm<4,up2>" : NT == 2 ? "k_igemm<2,up2>" : "k_igemm<1,up2>")
                        : (NT == 4 ? "k_igemm<4>" : NT == 2 ? "k_igemm<2>" : "k_igemm<1>"), flops, bytes, s);
+    // the four-adjacent-pixels loader of the up-sampling form (k_igemm<.., 2>): see the kernel's header
+    const bool adj = up2 && stride == 1 && a.Wo % 4 == 0 && dil % 2 == 0 && a.pad_l % 2 == 0;
 #define SSAL_IG(N_)                                                                         \
-    if (up2) hipLaunchKernelGGL((k_igemm<N_, true>), dim3(grid), dim3(256), 0, s, a);      \
-    else hipLaunchKernelGGL((k_igemm<N_, false>), dim3(grid), dim3(256), 0, s, a)
+    if (adj) hipLaunchKernelGGL((k_igemm<N_, 2>), dim3(grid), dim3(256), 0, s, a);         \
+    else if (up2) hipLaunchKernelGGL((k_igemm<N_, 1>), dim3(grid), dim3(256), 0, s, a);    \
+    else hipLaunchKernelGGL((k_igemm<N_, 0>), dim3(grid), dim3(256), 0, s, a)
     if (NT == 4) { SSAL_IG(4); }
     else if (NT == 2) { SSAL_IG(2); }
     else { SSAL_IG(1); }

@@ -74,6 +74,10 @@ def _oracle_conv(x, k, stride, dil, bn, bias, res, relu, up2):
     (1, 256, 1024, 1, 1, 1, 4, 6, True, True, False),
     (3, 256, 128, 1, 2, 1, 5, 7, True, True, True),         # conv_sub4: 2x interp inside the conv + fusion add
     (3, 128, 128, 1, 2, 2, 6, 9, True, True, True),         # conv_sub2
+    (3, 128, 128, 1, 2, 2, 6, 10, True, True, True),        # Wo % 4 == 0: the four-adjacent-pixels loader (k_igemm<NT, 2>), all four borders
+    (3, 256, 128, 1, 2, 1, 5, 8, False, True, True),
+    (3, 32, 64, 1, 4, 1, 7, 6, False, False, True),         # dilation 4, padding 4, negative inputs kept (no ReLU upstream)
+    (3, 64, 96, 1, 2, 3, 1, 2, True, False, True),          # one source row, two source columns: every clamp at once
     (1, 128, 19, 1, 1, 1, 7, 5, False, False, True),        # conv6_cls: 2x interp + bias, 19 of 32 columns
     (1, 32, 5, 1, 1, 3, 3, 3, False, False, False),
     (3, 32, 32, 1, 1, 1, 130, 3, False, True, False),       # more pixels than one 128-row tile, ragged tail

@@ -197,14 +197,15 @@ int ssal_debug_probe(float *out_dev_256, void *stream);
  * XCD-aware tile order off, "img_groups": G runs the layers selected by "img_span" (default 4 = Initial .. Final + score) as G image
  * groups on G library-owned side streams, forked from / joined into the caller's stream with events -- default 2, 1 =
  * everything on the caller's stream; "ic_front": ICNet score path, bit 0 (default 1) = conv1_sub1 + conv2_sub1 as one launch,
- * bit 1 (default 0) = conv1_1_3x3_s2 + conv1_2_3x3 as one launch).  Every setting produces bit-identical results
+ * bit 1 (default 0) = conv1_1_3x3_s2 + conv1_2_3x3 as one launch; "ic_dual": ICNet score path, 1 (default) = a block's projection
+ * shortcut is evaluated inside its 1x1 increase launch).  Every setting produces bit-identical results
  * (tests/test_gpu_parity.py, tests/test_icnet_gpu.py); SSAL_EINVAL for
  * an unknown name.  The product build reads no environment variable and contains no work-skipping switch: phase
  * ablation ("ablate") and the SSAL_* environment defaults exist only in -DSSAL_MEASURE builds (tools/phase_trace.py),
  * whose ssal_version() says so. */
 int ssal_debug_set_knob(const char *name, int value);
 /* JSON object with the state of every switch that can change what a launch does or costs: kernel_family, bnk_tw, bnk_o4,
- * bnk_xcd, img_groups, img_span, fuse_ends, img_lag, ig_div, ic_front, ablate, measure_build, profiling, defaults (1 iff all are at their shipping values).  bench.py prints it
+ * bnk_xcd, img_groups, img_span, fuse_ends, img_lag, ig_div, ic_front, ic_dual, ablate, measure_build, profiling, defaults (1 iff all are at their shipping values).  bench.py prints it
  * in its result line and refuses to time anything else. */
 int ssal_debug_get_knobs(char *json_out, int64_t cap);
 

@@ -1211,6 +1211,7 @@ Knobs &knobs()
         q.img_lag = 0;
         q.ig_div = 0;
         q.ic_front = IC_FRONT_DEFAULT;
+        q.ic_dual = IC_DUAL_DEFAULT;
 #ifdef SSAL_MEASURE  // measurement builds only: the product library reads no environment
         auto env = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
         q.bnk_tw = env("SSAL_BNK_TW", 0);

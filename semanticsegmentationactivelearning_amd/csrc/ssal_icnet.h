@@ -16,6 +16,9 @@ struct IgemmArgs {
     const float *scale;  // [CoutP] (1.0 for the bias-only classifier)
     const float *shift;  // [CoutP]
     const float *res;    // [N,Ho,Wo,Cout] or NULL
+    // second source (k_igemm<.., DUAL>; NULL otherwise): y += fmaf(conv1x1_stride2(x2, wt2), scale2, shift2) instead of + res
+    const float *x2, *wt2, *scale2, *shift2;
+    int Cin2, H2, W2, stride2;
     int N, H, W, Cin, Ho, Wo, Cout, CoutP;
     int KH, KW, stride, dil, pad_t, pad_l;
     int relu;
@@ -33,6 +36,12 @@ struct IgemmArgs {
 size_t igemm_relayout_floats(int KH, int KW, int Cin, int Cout);
 void igemm_relayout(const float *w_hwio, int KH, int KW, int Cin, int Cout, float *out);
 bool igemm_supported(int Cin, int Cout, int KH, int KW);
+// a bottleneck's last 1x1 convolution (x -> y, stride 1) with its PROJECTION shortcut evaluated in the same launch:
+// y = [relu](fmaf(conv1x1(x, wt), scale, shift) + fmaf(conv1x1(xs[::stride_s, ::stride_s], wt_s), scale_s, shift_s));
+// xs = [N, H * stride_s, W * stride_s, Cin_s].  Bit-identical to launch_igemm(xs ...) -> t, launch_igemm(x ..., res = t).
+hipError_t launch_igemm_dual(const float *x, int N, int H, int W, int Cin, const float *wt, int Cout, const float *scale,
+                             const float *shift, const float *xs, int Cin_s, int stride_s, const float *wt_s,
+                             const float *scale_s, const float *shift_s, bool relu, float *y, hipStream_t s);
 hipError_t launch_igemm(const float *x, int N, int H, int W, int Cin, const float *wt, int KH, int KW, int Cout,
                         int stride, int dil, const float *scale, const float *shift, const float *res, bool relu,
                         bool up2, float *y, hipStream_t s);

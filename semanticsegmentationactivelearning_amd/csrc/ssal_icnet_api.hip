@@ -284,13 +284,22 @@ hipError_t run_trunk(const ssal_icnet *net, std::vector<Grp> &grp, bool x_is_u8,
             continue;
         }
         std::string shortcut = cur;
-        if (b.proj) {
+        // fused score path (knob ic_dual): the projection shortcut is evaluated inside the increase launch (k_igemm<.., DUAL>)
+        // and never reaches HBM
+        const bool dual = b.proj && fused && ssal::mfma_family() && ssal::knobs().ic_dual;
+        if (b.proj && !dual) {
             EACH(run_conv(net, nm + "_1x1_proj", q.A(cur), q.n, ch, cw, nullptr, false, false, q.A(nm + "_1x1_proj"), q.s));
             shortcut = nm + "_1x1_proj";
         }
         EACH(run_conv(net, nm + "_1x1_reduce", q.A(cur), q.n, ch, cw, nullptr, true, false, q.A(nm + "_1x1_reduce"), q.s));
         EACH(run_conv(net, nm + "_3x3", q.A(nm + "_1x1_reduce"), q.n, oh, ow, nullptr, true, false, q.A(nm + "_3x3"), q.s));
-        EACH(run_conv(net, nm + "_1x1_increase", q.A(nm + "_3x3"), q.n, oh, ow, q.A(shortcut), true, false, q.A(nm), q.s));
+        if (dual) {
+            const ConvDev &ci_ = net->convs.at(nm + "_1x1_increase"), &cp = net->convs.at(nm + "_1x1_proj");
+            EACH(launch_igemm_dual(q.A(nm + "_3x3"), q.n, oh, ow, ci_.spec.cin, ci_.w, ci_.spec.cout, ci_.scale, ci_.shift,
+                                   q.A(cur), cp.spec.cin, b.stride, cp.w, cp.scale, cp.shift, true, q.A(nm), q.s));
+        } else {
+            EACH(run_conv(net, nm + "_1x1_increase", q.A(nm + "_3x3"), q.n, oh, ow, q.A(shortcut), true, false, q.A(nm), q.s));
+        }
         cur = nm;
         ch = oh;
         cw = ow;

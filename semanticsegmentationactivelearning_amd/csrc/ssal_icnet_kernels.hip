@@ -51,9 +51,14 @@ constexpr unsigned IG_OOB = 0xFFFFFFFFu;  // a byte offset no tensor reaches: ra
 // for stride 1, even dilation / padding and Wo % 4 == 0 (ICNet's conv_sub4 / conv_sub2): a thread owns four ADJACENT output
 // pixels of one image row, whose taps interpolate from 3 source columns x 2 source rows -- 6 loads per chunk instead of 16,
 // same four source values and the same lerp formula per pixel, i.e. the same bits.
-template <int NT, int UP2>
-__global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
+// DUAL: two convolutions into one output (a bottleneck's projection shortcut + its 1x1 "increase"; score path only): pass 0
+// runs the SECOND source (a0.x2: 1x1, stride a0.stride2, its own folded batch-norm) through the same K loop and parks
+// y_p = fmaf(acc, scale2, shift2) in registers, pass 1 runs the main convolution and adds y_p where the separate launches
+// add the shortcut tensor they read back -- the same arithmetic, without the shortcut's write + read.
+template <int NT, int UP2, bool DUAL = false>
+__global__ __launch_bounds__(256) void k_igemm(IgemmArgs a0)
 {
+    IgemmArgs a = a0;
     constexpr int BM = IG_BM, BN = 32 * NT, LDK = IG_LDK;
     // The kernel tiles (B) are always stored permuted (free: done once at commit).  The activation tile (A) is
     // permuted while it is written to LDS when that pays: two 8-byte LDS writes per quad instead of one 16-byte
@@ -79,6 +84,27 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
     const int n0 = tn * BN;
     const int M = (int)a.M;
 
+    f32x16 acc[NT];
+    float yp[DUAL ? NT : 1][16];  // DUAL: the shortcut branch's output for this lane's 16 pixels x NT columns
+#ifdef SSAL_PHASE_TRACE  // tools/igemm_trace.py: per-wave cycle totals of the phases of the K loop
+    unsigned long long tr_t0 = __builtin_amdgcn_s_memtime(), tr_r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tr_gl = 0, tr_mm = 0, tr_vm = 0, tr_wr = 0, tr_bar = 0, tr_a, tr_b;
+#define TR_MARK(acc_)  do { tr_b = __builtin_amdgcn_s_memtime(); acc_ += tr_b - tr_a; tr_a = tr_b; } while (0)
+#else
+#define TR_MARK(acc_)  do { } while (0)
+#endif
+#ifdef SSAL_PHASE_TRACE
+    unsigned long long tr_loop = 0, tr_loop_end = 0;
+#endif
+#pragma unroll 1
+    for (int pass = DUAL ? 0 : 1; pass < 2; ++pass) {
+    if (DUAL) {
+        a = a0;
+        if (pass == 0) {  // the shortcut branch: 1x1, no padding, its own stride / input
+            a.x = a0.x2; a.wt = a0.wt2; a.Cin = a0.Cin2; a.H = a0.H2; a.W = a0.W2; a.stride = a0.stride2;
+            a.KH = 1; a.KW = 1; a.dil = 1; a.pad_t = 0; a.pad_l = 0;
+        }
+    }
     const int Hs = UP2 ? a.H >> 1 : a.H, Ws = UP2 ? a.W >> 1 : a.W;  // dims of the tensor in memory (UP2: int, 0 / 1 / 2)
     const rsrc_t xrs = make_rsrc(a.x, (unsigned)((long)a.N * Hs * Ws * a.Cin * 4));
     const rsrc_t wrs = make_rsrc(a.wt, (unsigned)((long)a.KH * a.KW * a.Cin * a.CoutP * 4));
@@ -225,24 +251,15 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
     };
     auto lds_write = [&](int buf) { lds_write_a(buf); lds_write_b(buf); };
 
-    f32x16 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[nt][i] = 0.0f;
-
-#ifdef SSAL_PHASE_TRACE  // tools/igemm_trace.py: per-wave cycle totals of the phases of the K loop
-    unsigned long long tr_t0 = __builtin_amdgcn_s_memtime(), tr_r0 = __builtin_amdgcn_s_memrealtime();
-    unsigned long long tr_gl = 0, tr_mm = 0, tr_vm = 0, tr_wr = 0, tr_bar = 0, tr_a, tr_b;
-#define TR_MARK(acc_)  do { tr_b = __builtin_amdgcn_s_memtime(); acc_ += tr_b - tr_a; tr_a = tr_b; } while (0)
-#else
-#define TR_MARK(acc_)  do { } while (0)
-#endif
     gload(true);
     lds_write(0);
     __syncthreads();
 #ifdef SSAL_PHASE_TRACE
-    const unsigned long long tr_loop = __builtin_amdgcn_s_memtime();
+    tr_loop = __builtin_amdgcn_s_memtime();
     tr_a = tr_loop;
 #endif
     for (int t = 0; t < nchunks; ++t) {
@@ -326,8 +343,17 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
         TR_MARK(tr_bar);
     }
 #ifdef SSAL_PHASE_TRACE
-    const unsigned long long tr_loop_end = __builtin_amdgcn_s_memtime();
+    tr_loop_end = __builtin_amdgcn_s_memtime();
 #endif
+    if (DUAL && pass == 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float sc2 = a0.scale2[n0 + 32 * nt + r], sh2 = a0.shift2[n0 + 32 * nt + r];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) yp[DUAL ? nt : 0][i] = fmaf(acc[nt][i], sc2, sh2);
+        }
+    }
+    }  // pass
 
     // ---- epilogue: folded batch-norm, shortcut add, ReLU, store (128-B rows per lane half) --------
     const unsigned ybytes = (unsigned)(a.M * a.Cout * 4);
@@ -345,14 +371,17 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a)
         const float sc = a.scale[co], sh = a.shift[co];
         const bool cok = co < a.Cout;
         float rv[16];
-        if (a.res) {  // wave-uniform
+        if (DUAL) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) rv[i] = yp[DUAL ? nt : 0][i];
+        } else if (a.res) {  // wave-uniform
 #pragma unroll
             for (int i = 0; i < 16; ++i) rv[i] = bload(rrs, (cok && moff[i] != IG_OOB) ? moff[i] + 4u * co : IG_OOB, 0);
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             float v = fmaf(acc[nt][i], sc, sh);
-            if (a.res) v = v + rv[i];
+            if (DUAL || a.res) v = v + rv[i];
             if (a.relu) v = v > 0.0f ? v : 0.0f;
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs,
                                                   (cok && moff[i] != IG_OOB) ? moff[i] + 4u * co : IG_OOB, 0, 0);
@@ -730,6 +759,40 @@ hipError_t launch_igemm(const float *x, int N, int H, int W, int Cin, const floa
     else if (NT == 2) { SSAL_IG(2); }
     else { SSAL_IG(1); }
 #undef SSAL_IG
+    return hipGetLastError();
+}
+
+hipError_t launch_igemm_dual(const float *x, int N, int H, int W, int Cin, const float *wt, int Cout, const float *scale,
+                             const float *shift, const float *xs, int Cin_s, int stride_s, const float *wt_s,
+                             const float *scale_s, const float *shift_s, bool relu, float *y, hipStream_t s)
+{
+    if (!igemm_supported(Cin, Cout, 1, 1) || !igemm_supported(Cin_s, Cout, 1, 1) || stride_s < 1) return hipErrorInvalidValue;
+    IgemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.wt = wt; a.y = y; a.scale = scale; a.shift = shift; a.res = nullptr;
+    a.x2 = xs; a.wt2 = wt_s; a.scale2 = scale_s; a.shift2 = shift_s;
+    a.Cin2 = Cin_s; a.H2 = H * stride_s; a.W2 = W * stride_s; a.stride2 = stride_s;
+    a.N = N; a.Cin = Cin; a.Cout = Cout; a.CoutP = (Cout + 31) / 32 * 32;
+    a.H = H; a.W = W; a.KH = 1; a.KW = 1; a.stride = 1; a.dil = 1; a.relu = relu ? 1 : 0;
+    a.Ho = H; a.Wo = W; a.M = (long)N * H * W;
+    const int cmax = Cin > Cin_s ? Cin : Cin_s;
+    if (cmax > 2048 || (long)N * a.H2 * a.W2 * Cin_s * 4 >= (1L << 32) - 16384 || (long)N * H * W * Cin * 4 >= (1L << 32) - 16384 ||
+        a.M * Cout * 4 >= (1L << 32) - 256 || a.M >= (1L << 31) - 256)
+        return hipErrorInvalidValue;
+    a.tiles_m = cdiv_i(a.M, IG_BM);
+    const int nb32 = a.CoutP / 32;
+    int NT = nb32 % 4 == 0 ? 4 : (nb32 % 2 == 0 ? 2 : 1);
+    while (NT > 1 && (long)a.tiles_m * (nb32 / NT) < 512 / launch_concurrency()) NT >>= 1;
+    a.tiles_n = nb32 / NT;
+    a.ntiles = a.tiles_m * a.tiles_n;
+    a.xcd_chunk = (a.ntiles + 7) / 8;
+    const int grid = a.xcd_chunk * 8;
+    const double flops = 2.0 * (double)a.M * (Cin + Cin_s) * Cout;
+    const double bytes = 4.0 * ((double)N * H * W * Cin + (double)N * H * W * Cin_s + (double)a.M * Cout + (double)(Cin + Cin_s) * Cout);
+    ProfScope prof(NT == 4 ? "k_igemm<4,dual>" : NT == 2 ? "k_igemm<2,dual>" : "k_igemm<1,dual>", flops, bytes, s);
+    if (NT == 4) hipLaunchKernelGGL((k_igemm<4, 0, true>), dim3(grid), dim3(256), 0, s, a);
+    else if (NT == 2) hipLaunchKernelGGL((k_igemm<2, 0, true>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_igemm<1, 0, true>), dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -523,3 +523,31 @@ def test_fused_branch_fronts_are_bit_identical(icnet19, n, h, w, u8):
     finally:
         _lib.set_knob("img_groups", 2)
         _lib.set_knob("ic_front", shipped)
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 64, 96), (1, 32, 32), (3, 160, 224)])
+def test_projection_shortcut_inside_the_increase_launch_is_bit_identical(icnet19, n, h, w):
+    """knob ic_dual: the four blocks with a projection shortcut (conv2_1, conv3_1 -- stride 2 --, conv4_1, conv5_1) evaluate
+    the projection inside their 1x1 increase launch (k_igemm<.., DUAL>) instead of writing it and reading it back: block
+    outputs, scores, labels and confidences must be the same bits, with one and with two image chains."""
+    net, _ = icnet19
+    x = syn.synth_frames_device(21, n, h, w, 3)
+    shipped = _lib.get_knobs()["ic_dual"]
+    blocks = ("conv2_1", "conv3_1", "conv4_1", "conv5_1", "conv5_3")
+    try:
+        _lib.set_knob("img_groups", 1)
+        _lib.set_knob("ic_dual", 0)
+        s0, e0 = net.score(x, "margin", return_label=True, return_confidence=True)
+        want = {k: net.endpoint(k).clone() for k in blocks}
+        _lib.set_knob("ic_dual", 1)
+        for groups in (1, 2):
+            _lib.set_knob("img_groups", groups)
+            s, e = net.score(x, "margin", return_label=True, return_confidence=True)
+            assert torch.equal(s, s0) and torch.equal(e["label"], e0["label"]) and torch.equal(e["confidence"], e0["confidence"]), \
+                "ic_dual=1 img_groups=%d changes the result" % groups
+            if groups == 1:
+                for k, t in want.items():
+                    assert torch.equal(net.endpoint(k), t), "ic_dual=1: %s differs" % k
+    finally:
+        _lib.set_knob("img_groups", 2)
+        _lib.set_knob("ic_dual", shipped)

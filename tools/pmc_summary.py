@@ -22,8 +22,11 @@ def short(name):
         return n.replace(" ", "")
     if n.startswith("k_final_score"):  # k_final_score<19, false, true> = Bottleneck5_1 evaluated inside (bench: "k_final_score<fused 5_1>")
         return "k_final_score<fused 5_1>" if n.replace(" ", "").endswith(",true>") else "k_final_score"
-    if n.startswith("k_igemm"):
-        return n.split(",")[0] + (",up2>" if "true" in n else ">")  # k_igemm<4, true> -> k_igemm<4,up2>;  <4, false> -> k_igemm<4>
+    if n.startswith("k_igemm"):  # k_igemm<NT, UP2 (0 / 1 / 2), DUAL> -> the launchers' profile names k_igemm<4>, <4,up2>, <4,dual>
+        args = [t.strip() for t in n[n.index("<") + 1:n.rindex(">")].split(",")]
+        up2 = len(args) > 1 and args[1] in ("1", "2", "true")
+        dual = len(args) > 2 and args[2] == "true"
+        return "k_igemm<%s%s%s>" % (args[0], ",up2" if up2 else "", ",dual" if dual else "")
     return n.split("<")[0]
 
 

@@ -67,6 +67,8 @@ def _oracle_conv(x, k, stride, dil, bn, bias, res, relu, up2):
     (3, 32, 64, 1, 1, 2, 7, 9, False, True, False),
     (3, 32, 32, 2, 1, 1, 16, 24, False, True, False),       # conv2_sub1
     (3, 32, 32, 2, 1, 1, 15, 11, False, True, False),       # odd dims: SAME pads (1, 1)
+    (3, 32, 64, 2, 1, 2, 36, 50, False, True, False),       # conv3_sub1's shape: two column tiles, ragged 18 x 25 output
+    (3, 32, 19, 2, 1, 1, 2, 2, False, False, False),        # one output pixel, 19 of 32 columns, no ReLU
     (3, 64, 64, 1, 1, 1, 6, 8, False, True, False),
     (3, 128, 128, 1, 2, 1, 12, 16, False, True, False),     # dilation 2 (conv4)
     (3, 256, 256, 1, 4, 1, 9, 10, False, True, False),      # dilation 4 (conv5)

@@ -59,11 +59,14 @@ int ssal_icnet_score_nhwc_u8(ssal_icnet *net, const uint8_t *x_dev, int n, int h
  * after a FORWARD call; a SCORE call runs conv2_2 / conv2_3 as one fused launch each and conv1_sub1 + conv2_sub1 as one
  * (k_front2, csrc/ssal_icnet_front.hip; knob "ic_front", include/ssal_enet.h), so the *_1x1_reduce / *_3x3 buffers of those
  * two blocks, conv1_sub1's and the four *_1x1_proj buffers (knob "ic_dual": the projection shortcut is evaluated inside the
- * increase launch) keep whatever an earlier call left there (stale) -- inspect layer outputs after ssal_icnet_forward_nhwc. */
+ * increase launch) keep whatever an earlier call left there (stale) -- inspect layer outputs after ssal_icnet_forward_nhwc.
+ * ssal_icnet_endpoint_valid_after_score answers, for one name and frame size and the knobs as they are now: 1 = a score
+ * call writes it, 0 = a fused launch swallows it, -1 = unknown name / bad arguments (models.ICNet.endpoint raises on 0). */
 int ssal_icnet_num_endpoints(const ssal_icnet *net);
 int ssal_icnet_endpoint_name(const ssal_icnet *net, int i, const char **name);
 int ssal_icnet_endpoint_info(const ssal_icnet *net, const char *name, int n, int h, int w, int64_t *offset,
                              int64_t dims[4]);
+int ssal_icnet_endpoint_valid_after_score(const ssal_icnet *net, const char *name, int h, int w);
 
 /* Stand-alone fused convolution (the operator every ICNet layer is built from; also the per-block parity hook):
  * y = [relu]( BN(conv2d(x, kernel HWIO, strides s, dilations d, "SAME")) [+ res] ), BN given as mean / variance /

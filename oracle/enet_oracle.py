@@ -39,12 +39,39 @@ def build(force=False):
     return _SO
 
 
+def usable_cores(cap=None):
+    """CPU threads this process may really use: min(affinity, cgroup quota[, cap]) -- the oracle's own copy (test
+    infrastructure imports nothing from the product package)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota> <period>" or "max <period>"
+            q, p = f.read().split()[:2]
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    env = os.environ.get("SSAL_CPU_THREADS")
+    if env:
+        n = min(n, max(1, int(env)))
+    if cap:
+        n = min(n, cap)
+    return max(1, n)
+
+
 def _lib():
     global _LIB
     if _LIB is None:
         build()
         if "OMP_NUM_THREADS" not in os.environ:  # size the OpenMP pool to the box's real CPU share
-            from semanticsegmentationactivelearning_amd._lib import usable_cores
             os.environ["OMP_NUM_THREADS"] = str(usable_cores(cap=32))
         _LIB = ctypes.CDLL(_SO)
     return _LIB

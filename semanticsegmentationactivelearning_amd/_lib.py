@@ -5,12 +5,70 @@ or a call fails, the error is raised loudly.
 """
 import ctypes
 import os
+import sys
+import warnings
 
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SSAL_LIB_PATH: measurement builds only (tools/phase_trace.py loads a -DSSAL_PHASE_TRACE build)
 LIB_PATH = os.environ.get("SSAL_LIB_PATH") or os.path.join(_HERE, "libssal_hip.so")
+
+# ---- process environment the HIP runtime reads ONCE, when it comes up ------------------------------------------------
+# GPU_MAX_HW_QUEUES: streams -> hardware queues, runtime default 4 per process.  A ranking job under torch.distributed.run
+# drives the caller's stream + 2 image-group side streams + a prefetch copy stream + RCCL's stream = 5; with 2 queues (or an
+# EMPTY variable) two chains share a queue and the pass loses 11 % (profiles/r04_ab_hw_queues.txt; 4 = 8 = 16 at N = 1).
+# HSA_ENABLE_IPC_MODE_LEGACY=0: the pool's host driver only supports dmabuf IPC (RCCL across the ranks of one node).
+# Both are defaulted here, at import, while the runtime is still down; once a HIP context exists they can no longer take
+# effect and `warn_if_few_hw_queues` (called by rank_confidence under a process group) says so instead.
+MIN_HW_QUEUES = 5
+ENV_INJECTED = {}
+
+
+def _hip_is_up():
+    t = sys.modules.get("torch")
+    try:
+        return bool(t is not None and t.cuda.is_initialized())
+    except Exception:
+        return False
+
+
+def _default_runtime_env():
+    if _hip_is_up():
+        return
+    if not os.environ.get("GPU_MAX_HW_QUEUES"):  # unset OR empty (an empty value was measured to behave like 2)
+        os.environ["GPU_MAX_HW_QUEUES"] = "8"
+        ENV_INJECTED["GPU_MAX_HW_QUEUES"] = "8"
+    if "HSA_ENABLE_IPC_MODE_LEGACY" not in os.environ:
+        os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        ENV_INJECTED["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+
+
+_default_runtime_env()
+_warned_hw_queues = False
+
+
+def hw_queues_ok():
+    """True when GPU_MAX_HW_QUEUES is set to >= MIN_HW_QUEUES in this process' environment"""
+    v = os.environ.get("GPU_MAX_HW_QUEUES", "")
+    try:
+        return int(v) >= MIN_HW_QUEUES
+    except ValueError:
+        return False
+
+
+def warn_if_few_hw_queues():
+    """once per process: the N > 1 ranking loop needs 5 concurrent streams (see above)"""
+    global _warned_hw_queues
+    if _warned_hw_queues or hw_queues_ok():
+        return False
+    _warned_hw_queues = True
+    warnings.warn("GPU_MAX_HW_QUEUES=%r: a sharded ranking pass drives 5 HIP streams (caller + 2 image-group chains + "
+                  "prefetch copy + RCCL); with fewer hardware queues two of them serialise (-11 %% measured).  Export "
+                  "GPU_MAX_HW_QUEUES=8, or import semanticsegmentationactivelearning_amd before the first HIP call."
+                  % os.environ.get("GPU_MAX_HW_QUEUES"), RuntimeWarning, stacklevel=3)
+    return True
+
 
 SSAL_OK, SSAL_EINVAL, SSAL_EHIP, SSAL_ENOTIMPL, SSAL_ESTATE, SSAL_ENOMEM = range(6)
 
@@ -72,6 +130,7 @@ PROTOTYPES = {
     "ssal_icnet_num_endpoints": (_i, [_vp]),
     "ssal_icnet_endpoint_name": (_i, [_vp, _i, _c.POINTER(_c.c_char_p)]),
     "ssal_icnet_endpoint_info": (_i, [_vp, _c.c_char_p, _i, _i, _i, _c.POINTER(_i64), _c.POINTER(_i64)]),
+    "ssal_icnet_endpoint_valid_after_score": (_i, [_vp, _c.c_char_p, _i, _i]),
     "ssal_conv_bn_workspace_bytes": (_i64, [_i, _i, _i, _i]),
     "ssal_conv_bn_act": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
                               _vp, _vp, _i64, _vp]),
@@ -202,7 +261,9 @@ class DeviceState:
       and pushes the weights to a device the first time it is used there (and again after any variable changed);
     * concurrent calls on one handle need their own workspace: workspaces are keyed by (device, current torch stream),
       so two host threads scoring on two streams never share one (the header's re-entrancy contract).
-    ``_ws`` / ``_last_dims`` always describe the MOST RECENT call (endpoint views, ``pooling_argmax``).
+    "The most recent call" (endpoint views, ``pooling_argmax``) means the CALLING THREAD's most recent call: ``_ws`` /
+    ``_last_dims`` / ``_last_call`` are one record ``(workspace, dims, device, kind)`` kept per thread, so two threads that
+    score on one model never pair one's dims with the other's workspace.
 
     The model provides ``_create_handle(L) -> c_void_p``, ``_push_tensors(L, handle)`` (set_tensor + commit),
     ``_destroy_handle(L, handle)`` and ``variables``."""
@@ -213,17 +274,39 @@ class DeviceState:
         import threading
         self._handles = {}        # device ordinal -> [handle, pushed_versions]
         self._workspaces = {}     # (device ordinal, stream pointer) -> uint8 tensor, in least-recently-used order
-        self._ws = None
-        self._last_dims = None
+        self._tls = threading.local()  # .last = (workspace, dims, device ordinal, "forward" | "score" | "layer")
         self._state_lock = threading.Lock()
+
+    # ---- the calling thread's most recent call ----
+    def _note_call(self, ws, dims, kind):
+        dev = ws.device.index if ws is not None else None
+        self._tls.last = (ws, dims, dev, kind)
+
+    @property
+    def _last(self):
+        return getattr(self._tls, "last", (None, None, None, None))
+
+    @property
+    def _ws(self):
+        return self._last[0]
+
+    @property
+    def _last_dims(self):
+        return self._last[1]
+
+    @property
+    def _last_call(self):
+        return self._last[3]
 
     @property
     def _handle(self):
-        """the handle of the current device (None before the first call there)"""
+        """the handle of the device the calling thread's most recent call ran on (else of the current device); None when
+        there is none -- never another device's handle"""
         torch = _torch()
-        ent = self._handles.get(torch.cuda.current_device()) if torch.cuda.is_available() else None
-        if ent is None and self._handles:
-            ent = next(iter(self._handles.values()))
+        dev = self._last[2]
+        if dev is None and torch.cuda.is_available():
+            dev = torch.cuda.current_device()
+        ent = self._handles.get(dev)
         return ent[0] if ent else None
 
     def _sync_handle(self):
@@ -249,8 +332,6 @@ class DeviceState:
         with self._state_lock:
             ws = self._workspaces.pop(key, None)
             if ws is None or ws.numel() < nbytes:
-                if self._ws is ws:
-                    self._ws = None
                 del ws  # release before growing
                 # a workspace is 1.8 GB at batch 8 x 1024 x 2048: a caller that cycles through many streams must not pin
                 # one per stream for ever.  Dropping the tensor is safe while its stream still runs: the caching
@@ -258,12 +339,9 @@ class DeviceState:
                 while len(self._workspaces) >= self.MAX_WORKSPACES:
                     old_key = next(iter(self._workspaces))
                     old = self._workspaces.pop(old_key)
-                    if self._ws is old:
-                        self._ws = None
-                    del old
+                    del old  # (a thread whose last call used it keeps its own reference until its next call)
                 ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
             self._workspaces[key] = ws  # most recently used last
-            self._ws = ws
             return ws
 
     def _release_device_state(self):
@@ -328,6 +406,9 @@ def get_knobs():
     check(lib().ssal_debug_get_knobs(buf, len(buf)))
     out = json.loads(buf.value.decode())
     out["version"] = lib().ssal_version().decode()
+    # the runtime environment belongs to "what a launch does" too: which values this package injected at import
+    inj = sorted(set(ENV_INJECTED) | ({"GPU_MAX_HW_QUEUES"} if os.environ.get("SSAL_BENCH_INJECTED_HWQ") else set()))
+    out["env"] = {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "injected": inj}
     return out
 
 

@@ -199,6 +199,9 @@ def rank_confidence(net, batches, num_examples, unlabelled, selection_size, meas
     collective, so nobody is left blocking in it.  ``ragged=True`` is for callers that split the pool some other way
     (shard lengths unknown to the other ranks): it costs one extra all-reduce(MAX) to agree on the length."""
     torch = _lib.require_gpu()
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        _lib.warn_if_few_hw_queues()  # caller + 2 chains + prefetch copy + RCCL = 5 streams (once per process)
     idx_chunks, score_chunks = [], []
     if prefetch > 0:
         batches = prefetch_to_device(batches, depth=prefetch)

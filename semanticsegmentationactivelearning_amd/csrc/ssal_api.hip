@@ -642,14 +642,21 @@ NetWorkspace carve(const ssal_enet *net, void *ws, int64_t ws_bytes, int64_t n, 
     return W;
 }
 
-int check_dims(const ssal_enet *net, int n, int h, int w)
+// every entry point that launches against the handle's weight arena: the arena lives on ONE device
+int check_device(const ssal_enet *net)
 {
-    if (!net) return fail(SSAL_EINVAL, "net is NULL");
-    if (!net->committed) return fail(SSAL_ESTATE, "ssal_enet_commit() has not been called");
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev != net->device)
         return fail(SSAL_ESTATE, "the handle was committed on device %d but the current device is %d (one handle per device)",
                     net->device, dev);
+    return SSAL_OK;
+}
+
+int check_dims(const ssal_enet *net, int n, int h, int w)
+{
+    if (!net) return fail(SSAL_EINVAL, "net is NULL");
+    if (!net->committed) return fail(SSAL_ESTATE, "ssal_enet_commit() has not been called");
+    if (int rc = check_device(net)) return rc;
     if (n <= 0 || h <= 0 || w <= 0) return fail(SSAL_EINVAL, "bad dims n=%d h=%d w=%d", n, h, w);
     if (h % 8 || w % 8)
         return fail(SSAL_EINVAL, "ENet needs H and W divisible by 8 (got %dx%d)", h, w);
@@ -927,6 +934,7 @@ SSAL_API int ssal_enet_run_layer(ssal_enet *net, const char *layer, const float 
 {
     if (!net || !layer) return fail(SSAL_EINVAL, "NULL argument");
     if (!net->committed) return fail(SSAL_ESTATE, "ssal_enet_commit() has not been called");
+    if (int rc = check_device(net)) return rc;
     if (!x_dev || !y_dev) return fail(SSAL_EINVAL, "NULL device pointer");
     if (n <= 0 || h <= 0 || w <= 0) return fail(SSAL_EINVAL, "bad dims n=%d h=%d w=%d", n, h, w);
     int li = find_layer(net, layer);

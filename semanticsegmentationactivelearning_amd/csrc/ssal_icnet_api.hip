@@ -10,6 +10,7 @@
 #include <math.h>
 
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -235,10 +236,17 @@ struct Grp {
 // path keeps one launch per ICNET_SPEC layer, so that every layer output of the last forward call is an endpoint.
 // Every layer is issued for all groups before the next layer (layer-major order: the chains advance together on their
 // streams instead of one chain's 70 launches queueing up in front of the other's).
-hipError_t run_trunk(const ssal_icnet *net, std::vector<Grp> &grp, bool x_is_u8, int h, int w, bool fused)
+// written != NULL: DRY run -- nothing is launched, the names of the activation buffers this schedule would write are
+// collected instead (ssal_icnet_endpoint_valid_after_score: the one place that knows which layer outputs a fused launch
+// swallows is the schedule itself)
+hipError_t run_trunk(const ssal_icnet *net, std::vector<Grp> &grp, bool x_is_u8, int h, int w, bool fused,
+                     std::set<std::string> *written = nullptr)
 {
+    const bool dry = written != nullptr;
+#define OUT(name) do { if (dry) written->insert(name); } while (0)
 #define EACH(expr)                                     \
     for (Grp & q : grp) {                              \
+        if (dry) break;                                \
         hipError_t e_ = (expr);                        \
         if (e_ != hipSuccess) return e_;               \
     }
@@ -248,13 +256,18 @@ hipError_t run_trunk(const ssal_icnet *net, std::vector<Grp> &grp, bool x_is_u8,
     const int front = fused && ssal::mfma_family() ? ssal::knobs().ic_front : 0;
     if ((front & 2) && front2_supported(h, w, net->c_in, 2, 1)) {
         const ConvDev &c = net->convs.at("conv1_1_3x3_s2"), &c2 = net->convs.at("conv1_2_3x3");
+        OUT("conv1_2_3x3");
         EACH(launch_front2(q.x, x_is_u8, q.n, h, w, net->c_in, 2, c.w, c.scale, c.shift, c2.w, c2.scale, c2.shift, 1,
                            q.A("conv1_2_3x3"), q.s));
     } else {
         const ConvDev &c = net->convs.at("conv1_1_3x3_s2");
+        OUT("conv1_1_3x3_s2");
+        OUT("conv1_2_3x3");
         EACH(launch_conv_first(q.x, x_is_u8, q.n, h, w, net->c_in, 2, c.w, c.scale, c.shift, q.A("conv1_1_3x3_s2"), q.s));
         EACH(run_conv(net, "conv1_2_3x3", q.A("conv1_1_3x3_s2"), q.n, h / 4, w / 4, nullptr, true, false, q.A("conv1_2_3x3"), q.s));
     }
+    OUT("conv1_3_3x3");
+    OUT("pool1_3x3_s2");
     EACH(run_conv(net, "conv1_3_3x3", q.A("conv1_2_3x3"), q.n, h / 4, w / 4, nullptr, true, false, q.A("conv1_3_3x3"), q.s));
     EACH(launch_maxpool3x3_s2(q.A("conv1_3_3x3"), q.n, h / 4, w / 4, 64, q.A("pool1_3x3_s2"), q.s));
     std::string cur = "pool1_3x3_s2";
@@ -264,6 +277,7 @@ hipError_t run_trunk(const ssal_icnet *net, std::vector<Grp> &grp, bool x_is_u8,
         const std::string nm = b.name;
         if (i == kStemBnecks) {
             // section 2: conv3_1_sub4 = resize_bilinear(conv3_1, 1/2)
+            OUT("conv3_1_sub4");
             EACH(launch_resize_bilinear(q.A(cur), q.n, ch, cw, 256, ch / 2, cw / 2, q.A("conv3_1_sub4"), q.s));
             cur = "conv3_1_sub4";
             ch /= 2;
@@ -277,6 +291,7 @@ hipError_t run_trunk(const ssal_icnet *net, std::vector<Grp> &grp, bool x_is_u8,
             // adds it into a +0-initialised chain)
             const ConvDev &r = net->convs.at(nm + "_1x1_reduce"), &c3 = net->convs.at(nm + "_3x3"),
                           &inc = net->convs.at(nm + "_1x1_increase");
+            OUT(nm);
             EACH(launch_bottleneck_mfma(q.A(cur), q.A(nm), q.n, ch, cw, b.cin, b.dil, r.w_hwio, r.scale, r.shift,
                                         net->zeros128, c3.w_hwio, nullptr, c3.scale, c3.shift, net->zeros128, inc.w_hwio,
                                         inc.scale, inc.shift, net->zeros128, q.s));
@@ -288,9 +303,13 @@ hipError_t run_trunk(const ssal_icnet *net, std::vector<Grp> &grp, bool x_is_u8,
         // and never reaches HBM
         const bool dual = b.proj && fused && ssal::mfma_family() && ssal::knobs().ic_dual;
         if (b.proj && !dual) {
+            OUT(nm + "_1x1_proj");
             EACH(run_conv(net, nm + "_1x1_proj", q.A(cur), q.n, ch, cw, nullptr, false, false, q.A(nm + "_1x1_proj"), q.s));
             shortcut = nm + "_1x1_proj";
         }
+        OUT(nm + "_1x1_reduce");
+        OUT(nm + "_3x3");
+        OUT(nm);
         EACH(run_conv(net, nm + "_1x1_reduce", q.A(cur), q.n, ch, cw, nullptr, true, false, q.A(nm + "_1x1_reduce"), q.s));
         EACH(run_conv(net, nm + "_3x3", q.A(nm + "_1x1_reduce"), q.n, oh, ow, nullptr, true, false, q.A(nm + "_3x3"), q.s));
         if (dual) {
@@ -305,18 +324,24 @@ hipError_t run_trunk(const ssal_icnet *net, std::vector<Grp> &grp, bool x_is_u8,
         cw = ow;
     }
     // pyramid pooling + conv5_4_k1
+    OUT("conv5_3_sum");
+    OUT("conv5_4_k1");
     EACH(launch_ppm(q.A(cur), q.n, ch, cw, 1024, q.W.pooled, q.A("conv5_3_sum"), q.s));
     EACH(run_conv(net, "conv5_4_k1", q.A("conv5_3_sum"), q.n, ch, cw, nullptr, true, false, q.A("conv5_4_k1"), q.s));
     // ---- high-resolution branch (section 3) ----
     if ((front & 1) && front2_supported(h, w, net->c_in, 1, 2)) {
         const ConvDev &c = net->convs.at("conv1_sub1"), &c2 = net->convs.at("conv2_sub1");
+        OUT("conv2_sub1");
         EACH(launch_front2(q.x, x_is_u8, q.n, h, w, net->c_in, 1, c.w, c.scale, c.shift, c2.w, c2.scale, c2.shift, 2,
                            q.A("conv2_sub1"), q.s));
     } else {
         const ConvDev &c = net->convs.at("conv1_sub1");
+        OUT("conv1_sub1");
+        OUT("conv2_sub1");
         EACH(launch_conv_first(q.x, x_is_u8, q.n, h, w, net->c_in, 1, c.w, c.scale, c.shift, q.A("conv1_sub1"), q.s));
         EACH(run_conv(net, "conv2_sub1", q.A("conv1_sub1"), q.n, h / 2, w / 2, nullptr, true, false, q.A("conv2_sub1"), q.s));
     }
+    for (const char *nm_ : {"conv3_sub1", "conv3_1_sub2_proj", "sub24_sum", "conv3_sub1_proj", "sub12_sum", "conv6_cls"}) OUT(nm_);
     EACH(run_conv(net, "conv3_sub1", q.A("conv2_sub1"), q.n, h / 4, w / 4, nullptr, true, false, q.A("conv3_sub1"), q.s));
     // ---- cascade feature fusion (section 4): the 2x interpolations are evaluated inside the dilated convs ----
     EACH(run_conv(net, "conv3_1_sub2_proj", q.A("conv3_1"), q.n, h / 16, w / 16, nullptr, false, false,
@@ -330,6 +355,7 @@ hipError_t run_trunk(const ssal_icnet *net, std::vector<Grp> &grp, bool x_is_u8,
     // sub12_sum_interp (2x) + conv6_cls (1x1, bias)
     EACH(run_conv(net, "conv6_cls", q.A("sub12_sum"), q.n, h / 8, w / 8, nullptr, false, true, q.A("conv6_cls"), q.s));
 #undef EACH
+#undef OUT
     return hipSuccess;
 }
 
@@ -596,6 +622,22 @@ SSAL_API int ssal_icnet_endpoint_info(const ssal_icnet *net, const char *name, i
         }
     }
     return fail(SSAL_EINVAL, "'%s' is not a materialised ICNet tensor", name);
+}
+
+// 1: a SCORE call at h x w (with the knobs as they are now) writes the named endpoint; 0: a fused launch swallows it (its
+// buffer keeps whatever an earlier call left); -1 (+ last error): unknown name / bad arguments
+SSAL_API int ssal_icnet_endpoint_valid_after_score(const ssal_icnet *net, const char *name, int h, int w)
+{
+    if (!net || !name) { (void)fail(SSAL_EINVAL, "NULL argument"); return -1; }
+    if (!net->committed) { (void)fail(SSAL_ESTATE, "ssal_icnet_commit() has not been called"); return -1; }
+    if (h <= 0 || w <= 0 || h % 32 || w % 32) { (void)fail(SSAL_EINVAL, "bad dims h=%d w=%d", h, w); return -1; }
+    bool known = false;
+    for (const ActSpec &a : net->acts) known = known || a.name == name;
+    if (!known) { (void)fail(SSAL_EINVAL, "'%s' is not a materialised ICNet tensor", name); return -1; }
+    std::set<std::string> written;
+    std::vector<Grp> none;
+    (void)run_trunk(net, none, false, h, w, true, &written);
+    return written.count(name) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------

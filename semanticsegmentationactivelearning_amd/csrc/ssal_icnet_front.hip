@@ -337,6 +337,7 @@ hipError_t launch_front2(const void *x, bool x_is_u8, int N, int H, int W, int C
     if (tiles >= (1L << 31) || (long)H * W * Cin * 4 >= (1L << 31)) return hipErrorInvalidValue;
     // persistent workgroups, two per CU over all chains that run side by side
     long grid = 512 / launch_concurrency();
+    if (grid < 1) grid = 1;  // knob ig_div > 512: the launch degrades, it does not fail
     if (grid > tiles) grid = tiles;
     const double px1 = (double)N * a.H1 * a.W1, px2 = (double)N * a.H2 * a.W2;
     ProfScope prof(stride2 == 2 ? "k_front2<s2>" : "k_front2<s1>", 2.0 * px1 * 9 * Cin * 32 + 2.0 * px2 * 9 * 32 * 32,

@@ -178,8 +178,8 @@ class ENet(_lib.DeviceState):
             fwd = L.ssal_enet_forward_nhwc_u8 if x.dtype == torch.uint8 else L.ssal_enet_forward_nhwc
             _lib.check(fwd(handle, _lib.dev_ptr(x), n, h, w, _lib.dev_ptr(logits),
                            _lib.dev_ptr(ws), ws.numel(), _lib.stream_ptr()))
-            self._record_endpoints(logits, ws, n, h, w)
-            self._last_dims = (n, h, w)
+            self._note_call(ws, (n, h, w), "forward")
+            self._record_endpoints(handle, logits, ws, n, h, w)
         # The reference appends one symbolic tensor per graph build (enet.py:405); this implementation is
         # eager, so retaining every call's logits would grow device memory without bound (1.27 GB per batch
         # of 8 at 1024x2048x19): only the most recent call is kept.
@@ -188,10 +188,10 @@ class ENet(_lib.DeviceState):
 
     call = __call__
 
-    def _record_endpoints(self, final, ws, n, h, w):
+    def _record_endpoints(self, handle, final, ws, n, h, w):
         torch = _lib.require_gpu()
         offs = (ctypes.c_int64 * 3)()
-        _lib.check(_lib.lib().ssal_enet_endpoint_offsets(self._handle, n, h, w, offs))
+        _lib.check(_lib.lib().ssal_enet_endpoint_offsets(handle, n, h, w, offs))
         shapes = [(n, h // 2, w // 2, 16), (n, h // 4, w // 4, 64), (n, h // 8, w // 8, 128)]
         views = []
         for off, shp in zip(offs, shapes):
@@ -246,7 +246,7 @@ class ENet(_lib.DeviceState):
                 handle, _lib.dev_ptr(x), n, h, w, _lib.MEASURES[measure], float(threshold),
                 _lib.dev_ptr(scores, torch.float64, "scores"), _lib.dev_ptr(label), _lib.dev_ptr(mask),
                 _lib.dev_ptr(conf), _lib.dev_ptr(ws), ws.numel(), _lib.stream_ptr()))
-            self._last_dims = (n, h, w)
+            self._note_call(ws, (n, h, w), "score")
         if return_label or return_mask or return_confidence:
             return scores, {"label": label, "mask": mask, "confidence": conf}
         return scores
@@ -264,7 +264,7 @@ class ENet(_lib.DeviceState):
             name = layer.name.encode()
             nbytes = L.ssal_enet_layer_workspace_bytes(handle, name, n, h, w)
             ws = self._workspace(max(nbytes, 1024), x.device)
-            self._last_dims = None  # the single-layer call re-carves the workspace
+            self._note_call(ws, None, "layer")  # the single-layer call re-carves the workspace
             y = torch.empty(layer.output_shape(n, h, w), dtype=torch.float32, device=x.device)
             amax_out = None
             if want_argmax:

@@ -195,7 +195,7 @@ class ICNet(_lib.DeviceState):
             fwd = L.ssal_icnet_forward_nhwc_u8 if x.dtype == torch.uint8 else L.ssal_icnet_forward_nhwc
             _lib.check(fwd(handle, _lib.dev_ptr(x), n, h, w, _lib.dev_ptr(logits), _lib.dev_ptr(ws), ws.numel(),
                            _lib.stream_ptr()))
-            self._last_dims = (n, h, w)
+            self._note_call(ws, (n, h, w), "forward")
         self.outputs = [logits]  # eager: keep only the most recent call
         return logits
 
@@ -223,7 +223,7 @@ class ICNet(_lib.DeviceState):
             _lib.check(fn(handle, _lib.dev_ptr(x), n, h, w, _lib.MEASURES[measure], float(threshold),
                           _lib.dev_ptr(scores, torch.float64, "scores"), _lib.dev_ptr(label), _lib.dev_ptr(mask),
                           _lib.dev_ptr(conf), _lib.dev_ptr(ws), ws.numel(), _lib.stream_ptr()))
-            self._last_dims = (n, h, w)
+            self._note_call(ws, (n, h, w), "score")
         if return_label or return_mask or return_confidence:
             return scores, {"label": label, "mask": mask, "confidence": conf}
         return scores
@@ -240,14 +240,26 @@ class ICNet(_lib.DeviceState):
         return names
 
     def endpoint(self, name):
-        """view of the named ICNET_SPEC layer output of the most recent call (overwritten by the next one)"""
+        """view of the named ICNET_SPEC layer output of the calling thread's most recent call (overwritten by the next
+        one).  After ``__call__`` every layer output is materialised.  ``score()`` runs fused launches (branch fronts,
+        projection shortcuts inside the increase launch, whole identity blocks) that never write some layer outputs:
+        asking for one of those after a ``score()`` raises ``RuntimeError`` instead of handing out stale memory
+        (``ssal_icnet_endpoint_valid_after_score``, include/ssal_icnet.h)."""
         torch = _lib.require_gpu()
         if self._last_dims is None:
             raise RuntimeError("no forward pass has run yet")
         n, h, w = self._last_dims
+        L = _lib.lib()
+        if self._last_call == "score":
+            ok = L.ssal_icnet_endpoint_valid_after_score(self._handle, name.encode(), h, w)
+            if ok < 0:
+                _lib.check(_lib.SSAL_EINVAL)
+            if ok == 0:
+                raise RuntimeError("'%s' is not written by score() (it lives inside a fused launch); call the model "
+                                   "(forward) to materialise every layer output" % name)
         off = ctypes.c_int64()
         dims = (ctypes.c_int64 * 4)()
-        _lib.check(_lib.lib().ssal_icnet_endpoint_info(self._handle, name.encode(), n, h, w, ctypes.byref(off), dims))
+        _lib.check(L.ssal_icnet_endpoint_info(self._handle, name.encode(), n, h, w, ctypes.byref(off), dims))
         shp = tuple(int(d) for d in dims)
         cnt = shp[0] * shp[1] * shp[2] * shp[3]
         return self._ws[off.value:off.value + 4 * cnt].view(torch.float32).view(shp)

@@ -145,3 +145,60 @@ def test_bench_missing_rank_exits_nonzero_instead_of_hanging(tmp_path):
                         "--dist-timeout", "8", "--no-cpu-baseline", "--no-roofline"], env=env, capture_output=True, timeout=120)
     assert r.returncode != 0
     assert b"{\"metric\"" not in r.stdout
+
+
+def _prefetch_worker(rank, world, port, out_dir, pool_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import glob
+    import torch.distributed as dist
+    from helpers import make_model
+    from semanticsegmentationactivelearning_amd import _lib, active_learning as al
+    from semanticsegmentationactivelearning_amd.tensortools import InputStage
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        assert _lib.hw_queues_ok(), os.environ.get("GPU_MAX_HW_QUEUES")  # the package default (8), applied at import
+        net, _ = make_model(19, 3, seed=0)
+        files = np.array(sorted(glob.glob(os.path.join(pool_dir, "*.tfrecord"))))
+        pos = al.shard_positions(len(files), rank, world)
+        mine = pos[pos >= 0]
+        stage = InputStage(input_shape=[64, 64], image_dtype=np.uint8, pin_memory=True, pin_buffers=4)
+        stage.add_dataset_from_placeholders("train", files[mine], np.zeros(len(mine), dtype=bool), mine, batch_size=3)
+        stage.init_iterator("train", None, None)
+
+        def batches():
+            for image, label, mask, labelled, index in stage:
+                yield image, index
+        low, uconf = al.rank_confidence(net, batches(), len(files), np.arange(len(files)), 4, prefetch=2)
+        np.save(os.path.join(out_dir, "plow_%d.npy" % rank), np.sort(low))
+        np.save(os.path.join(out_dir, "puc_%d.npy" % rank), uconf)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_prefetch_from_tfrecords_five_streams(tmp_path):
+    """the five-stream case -- each of two ranks (sharing the one GPU, collectives over gloo) runs
+    rank_confidence(prefetch=2) on ITS shard of a pool of real TFRecords: caller's stream + 2 image-group chains + the
+    prefetch copy stream (+ the collective).  Both ranks must select what a single-process float32 pass selects."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import frames, make_model
+    from oracle import enet_oracle as orc
+    from test_input_cpu import write_pool
+    num, world = 13, 2
+    pool = tmp_path / "pool"
+    pool.mkdir()
+    write_pool(str(pool), num, 64, 64, with_label=False)
+    mp.spawn(_prefetch_worker, args=(world, _free_port(), str(tmp_path), str(pool)), nprocs=world, join=True)
+    lows = [np.load(tmp_path / ("plow_%d.npy" % r)) for r in range(world)]
+    ucs = [np.load(tmp_path / ("puc_%d.npy" % r)) for r in range(world)]
+    assert (lows[0] == lows[1]).all() and (ucs[0] == ucs[1]).all()
+    _, P = make_model(19, 3, seed=0)
+    want = orc.score_images(P, frames(np.arange(num), 64, 64, 3), "entropy")[0]
+    want_low, want_u = orc.rank_lowest(want, np.arange(num), 4)
+    srt = np.sort(want_u)
+    assert srt[4] - srt[3] > 1e-5, "fixture must separate the k-th boundary"
+    assert sorted(want_low.tolist()) == lows[0].tolist()
+    assert np.abs(ucs[0] - want_u).max() <= 1e-6

@@ -5,6 +5,8 @@ import json
 import os
 import re
 import subprocess
+import sys
+import time
 
 import numpy as np
 import pytest
@@ -379,3 +381,63 @@ def test_bench_line_is_compact_and_keeps_every_leg():
     assert "undefined" in line["secondary"]["c4"]["parity"]
     assert set(line["roofline_all"]) == set(full["roofline_all"])
     assert line["detail_file"] == os.path.join("gpurun_out", "bench_detail.json")
+
+
+def _import_env(env_extra, code):
+    """run `code` in a fresh interpreter (the runtime-environment defaults are applied once, at import)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "HSA_ENABLE_IPC_MODE_LEGACY", "SSAL_BENCH_INJECTED_HWQ")}
+    env.update(env_extra)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-W", "always", "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    return out.stdout.strip().splitlines()[-1], out.stderr
+
+
+def test_package_import_defaults_the_hip_runtime_environment():
+    """VERDICT r04 item 5a / ADVICE: a ranking job that only imports the package (not bench.py) must get the hardware-queue
+    count the bench measures.  Unset or EMPTY -> 8 (an empty value behaves like 2: -11 %); an explicit value is kept, and a
+    too small one is reported once by `warn_if_few_hw_queues` (what rank_confidence calls under a process group)."""
+    code = ("import os, json; from semanticsegmentationactivelearning_amd import _lib; "
+            "w = [_lib.warn_if_few_hw_queues(), _lib.warn_if_few_hw_queues()]; "
+            "print(json.dumps([os.environ.get('GPU_MAX_HW_QUEUES'), os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'), "
+            "sorted(_lib.ENV_INJECTED), w]))")
+    line, _ = _import_env({}, code)
+    assert json.loads(line) == ["8", "0", ["GPU_MAX_HW_QUEUES", "HSA_ENABLE_IPC_MODE_LEGACY"], [False, False]]
+    line, _ = _import_env({"GPU_MAX_HW_QUEUES": "", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, code)
+    assert json.loads(line) == ["8", "0", ["GPU_MAX_HW_QUEUES"], [False, False]]
+    line, err = _import_env({"GPU_MAX_HW_QUEUES": "2"}, code)
+    assert json.loads(line) == ["2", "0", ["HSA_ENABLE_IPC_MODE_LEGACY"], [True, False]]  # warned exactly once
+    assert err.count("GPU_MAX_HW_QUEUES='2'") == 1 and "RuntimeWarning" in err
+
+
+def test_last_call_state_is_per_thread_and_never_another_devices_handle():
+    """`_ws` / `_last_dims` / `_last_call` are ONE record per thread, and `_handle` has no any-device fallback"""
+    import threading
+
+    class Dummy(_lib.DeviceState):
+        pass
+
+    class FakeWs:
+        def __init__(self, idx):
+            class D:
+                index = idx
+            self.device = D()
+
+    d = Dummy()
+    d._init_device_state()
+    d._handles = {0: ["h0", None], 1: ["h1", None]}
+    seen = {}
+
+    def worker(tag, dev, dims):
+        d._note_call(FakeWs(dev), dims, "score")
+        time.sleep(0.05)
+        seen[tag] = (d._last_dims, d._last_call, d._handle, d._ws.device.index)
+
+    ts = [threading.Thread(target=worker, args=("a", 0, (1, 32, 32))), threading.Thread(target=worker, args=("b", 1, (2, 64, 64)))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert seen == {"a": ((1, 32, 32), "score", "h0", 0), "b": ((2, 64, 64), "score", "h1", 1)}
+    assert d._last_dims is None and d._ws is None  # this thread has made no call
+    d._handles = {3: ["h3", None]}
+    d._note_call(FakeWs(5), (1, 8, 8), "forward")
+    assert d._handle is None  # device 5 has no handle: None, not device 3's

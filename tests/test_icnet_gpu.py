@@ -553,3 +553,34 @@ def test_projection_shortcut_inside_the_increase_launch_is_bit_identical(icnet19
     finally:
         _lib.set_knob("img_groups", 2)
         _lib.set_knob("ic_dual", shipped)
+
+
+def test_endpoint_after_score_raises_for_layers_inside_fused_launches(icnet19):
+    """score() runs fused launches that never write some ICNET_SPEC layer outputs; endpoint() of such a name
+    after a score() must raise instead of returning a stale slice of the torch.empty workspace.  After a forward every
+    endpoint is valid again; the C answer (ssal_icnet_endpoint_valid_after_score) follows the knobs."""
+    net, _ = icnet19
+    x = dev(frames([0], 64, 64, 3))
+    net(x, training=False)
+    assert net.endpoint("conv1_sub1").shape == (1, 32, 32, 32)  # forward: materialised
+    net.score(x, measure="margin")
+    swallowed = [nm for nm in net.endpoint_names()
+                 if _lib.lib().ssal_icnet_endpoint_valid_after_score(net._handle, nm.encode(), 64, 64) == 0]
+    assert "conv1_sub1" in swallowed and "conv2_1_1x1_proj" in swallowed and "conv2_2_3x3" in swallowed
+    assert "conv6_cls" not in swallowed and "conv2_2" not in swallowed and "conv2_sub1" not in swallowed
+    for nm in swallowed:
+        with pytest.raises(RuntimeError, match="not written by score"):
+            net.endpoint(nm)
+    assert net.endpoint("conv6_cls").shape == (1, 16, 16, 19)
+    try:  # with the fused front and the dual launches off, those buffers ARE written by a score call
+        _lib.set_knob("ic_front", 0)
+        _lib.set_knob("ic_dual", 0)
+        net.score(x, measure="margin")
+        assert net.endpoint("conv1_sub1").shape == (1, 32, 32, 32) and net.endpoint("conv2_1_1x1_proj").shape[-1] == 128
+    finally:
+        _lib.set_knob("ic_front", 1)
+        _lib.set_knob("ic_dual", 1)
+    assert _lib.lib().ssal_icnet_endpoint_valid_after_score(net._handle, b"no_such_layer", 64, 64) == -1
+    net(x, training=False)
+    for nm in swallowed:
+        net.endpoint(nm)

@@ -44,6 +44,19 @@ extern "C" {
 #define SSAL_MEASURE_MARGIN      1
 #define SSAL_MEASURE_CONFIDENCE  2
 
+/* arithmetic modes of the *_arith entry points.
+ *   SSAL_ARITH_F32     the default and the only mode of every other entry point: exact fp32 (fmaf chains in (kh, kw, ci)
+ *                      order on v_mfma_f32_*), bit-identical to the parity oracle.
+ *   SSAL_ARITH_BF16X3  OPT-IN: the 128-channel regular / dilated / asymmetric bottlenecks (Bottleneck2_1 .. 3_8, 16 of the
+ *                      29 launches) evaluate their three convolutions on v_mfma_f32_32x32x16_bf16 with every fp32 operand
+ *                      split into three bf16 terms and the six leading cross products accumulated in fp32 (what is dropped
+ *                      is O(2^-24) relative per product).  Same accuracy class as fp32, a different summation: logits differ
+ *                      from the default mode by <= ~1e-5, per-pixel confidences by <= 1e-4 (north_star's tolerance), per-image
+ *                      scores by <= 1e-6; both pooling layers run in front of these blocks and stay exact, so the pooling
+ *                      indices are bit-identical.  No reference counterpart (the reference computes in fp32 on TensorFlow). */
+#define SSAL_ARITH_F32     0
+#define SSAL_ARITH_BF16X3  1
+
 typedef struct ssal_enet ssal_enet;
 
 const char *ssal_version(void);
@@ -92,6 +105,15 @@ int ssal_enet_score_nhwc_u8(ssal_enet *net, const uint8_t *x_dev, int n, int h, 
                             float threshold, double *scores_dev, uint8_t *label_dev, uint8_t *mask_dev,
                             float *conf_dev, void *ws_dev, int64_t ws_bytes, void *stream);
 
+/* forward / score with an explicit arithmetic mode (SSAL_ARITH_*); x_dev is float32 (x_is_u8 == 0) or the decoded uint8
+ * frame (x_is_u8 != 0).  arithmetic == SSAL_ARITH_F32 is exactly ssal_enet_forward_nhwc / ssal_enet_score_nhwc (_u8).
+ * Replaces the same reference code (models/enet/enet.py:320-407, active_learning.py:229-263). */
+int ssal_enet_forward_nhwc_arith(ssal_enet *net, const void *x_dev, int x_is_u8, int n, int h, int w, int arithmetic,
+                                 float *logits_dev, void *ws_dev, int64_t ws_bytes, void *stream);
+int ssal_enet_score_nhwc_arith(ssal_enet *net, const void *x_dev, int x_is_u8, int n, int h, int w, int measure,
+                               float threshold, int arithmetic, double *scores_dev, uint8_t *label_dev, uint8_t *mask_dev,
+                               float *conf_dev, void *ws_dev, int64_t ws_bytes, void *stream);
+
 /* Byte offsets into the workspace of the last forward/score call of the tensors behind
  * ENet.endpoint_outputs (models/enet/enet.py:311-318): offs[0] bottleneck5_1 [n,h/2,w/2,16],
  * offs[1] bottleneck4_2 [n,h/4,w/4,64], offs[2] bottleneck3_8 [n,h/8,w/8,128]. */
@@ -113,6 +135,10 @@ int ssal_enet_run_layer(ssal_enet *net, const char *layer, const float *x_dev, i
                         float *y_dev, int64_t *argmax_out_dev, const int64_t *argmax_in_dev,
                         void *ws_dev, int64_t ws_bytes, void *stream);
 int64_t ssal_enet_layer_workspace_bytes(const ssal_enet *net, const char *layer, int n, int h, int w);
+/* the same with an arithmetic mode (layers the mode has no kernel for run in exact fp32) */
+int ssal_enet_run_layer_arith(ssal_enet *net, const char *layer, const float *x_dev, int n, int h, int w, int arithmetic,
+                              float *y_dev, int64_t *argmax_out_dev, const int64_t *argmax_in_dev, void *ws_dev,
+                              int64_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Stand-alone operators

@@ -73,6 +73,15 @@ def warn_if_few_hw_queues():
 SSAL_OK, SSAL_EINVAL, SSAL_EHIP, SSAL_ENOTIMPL, SSAL_ESTATE, SSAL_ENOMEM = range(6)
 
 MEASURES = {"entropy": 0, "margin": 1, "confidence": 2}
+# include/ssal_enet.h SSAL_ARITH_*: "f32" = exact fp32, bit-identical to the oracle (default everywhere);
+# "bf16x3" = opt-in split-operand bf16 MFMAs in the 128-channel bottlenecks (within north_star's 1e-4, not bit-identical)
+ARITHMETICS = {"f32": 0, "bf16x3": 1}
+
+
+def arithmetic_code(arithmetic):
+    if arithmetic not in ARITHMETICS:
+        raise ValueError("arithmetic must be one of %s (got %r)" % (sorted(ARITHMETICS), arithmetic))
+    return ARITHMETICS[arithmetic]
 
 _c = ctypes
 _vp, _i, _i64, _f = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float
@@ -92,6 +101,9 @@ PROTOTYPES = {
     "ssal_enet_score_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "ssal_enet_forward_nhwc_u8": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i64, _vp]),
     "ssal_enet_score_nhwc_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "ssal_enet_forward_nhwc_arith": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i64, _vp]),
+    "ssal_enet_score_nhwc_arith": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "ssal_enet_run_layer_arith": (_i, [_vp, _c.c_char_p, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
     "ssal_enet_endpoint_offsets": (_i, [_vp, _i, _i, _i, _c.POINTER(_i64)]),
     "ssal_enet_export_argmax": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp]),
     "ssal_enet_run_layer": (_i, [_vp, _c.c_char_p, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),

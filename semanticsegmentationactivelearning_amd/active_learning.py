@@ -183,7 +183,7 @@ def pad_to_length(index, score, length):
 
 
 def rank_confidence(net, batches, num_examples, unlabelled, selection_size, measure="entropy",
-                    group=None, prefetch=0, ragged=False):
+                    group=None, prefetch=0, ragged=False, arithmetic="f32"):
     """Mirror of ``rank_confidence()`` (reference :682-715).
 
     ``batches`` yields ``(images NHWC float32 or uint8, example_indices)``; on a multi-GPU job each rank
@@ -192,6 +192,8 @@ def rank_confidence(net, batches, num_examples, unlabelled, selection_size, meas
     the ids (into the full example list) of the ``selection_size`` least confident unlabelled examples and
     the float32 confidence of every unlabelled example (the reference feeds it to a histogram summary,
     :781-784).
+
+    ``arithmetic`` is handed to ``net.score`` ("f32": exact fp32, the default; "bf16x3": ENet's opt-in split-operand mode).
 
     Collectives per ranking pass: exactly ONE all-gather of ``(index, score)`` pairs.  Shards handed out by
     ``shard_positions`` hold at most ``ceil(num_examples / world)`` examples, so each rank pads locally to that
@@ -206,7 +208,8 @@ def rank_confidence(net, batches, num_examples, unlabelled, selection_size, meas
     if prefetch > 0:
         batches = prefetch_to_device(batches, depth=prefetch)
     for images, indices in batches:
-        s = net.score(images, measure=measure)  # [n] float64 on device, stream-ordered
+        # [n] float64 on device, stream-ordered; arithmetic: "f32" (the reference's, default) or ENet's opt-in "bf16x3"
+        s = net.score(images, measure=measure) if arithmetic == "f32" else net.score(images, measure=measure, arithmetic=arithmetic)
         score_chunks.append(s)
         idx_chunks.append(torch.as_tensor(np.asarray(indices, dtype=np.int64), device=s.device))
     if score_chunks:

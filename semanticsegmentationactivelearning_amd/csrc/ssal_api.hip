@@ -4,6 +4,8 @@
 #include "ssal_internal.h"
 #include "ssal_host.h"
 #include "ssal_prof.h"
+#include "ssal_bottleneck_args.h"
+#include "ssal_bf16x3.h"
 
 #include <math.h>
 #include <stdarg.h>
@@ -104,6 +106,7 @@ struct DevLayer {
     const float *exp_w = nullptr, *exp_scale = nullptr, *exp_shift = nullptr;
     const float *res_w = nullptr, *res_alpha = nullptr;
     const float *convT_stacked = nullptr;  // Upsample: [6][f][2*cf] parity-stacked transposed-conv kernel
+    const float *bf3 = nullptr;  // SSAL_ARITH_BF16X3: the block's kernels pre-split into bf16 triples (ssal_bf16x3.h); NULL where the mode has no kernel
 };
 
 struct ssal_enet {
@@ -386,6 +389,12 @@ SSAL_API int ssal_enet_commit(ssal_enet *net, void *stream)
             o.v[12] = sp.kind == K_UP ? ab.push(T(net, n + "res_kernel")) : 0;
             o.v[13] = ab.push(T(net, n + "residual_alpha"));
             o.v[14] = sp.kind == K_UP ? ab.push(stack_convT(T(net, n + "conv_kernel"), cf, f)) : 0;
+            o.v[15] = 0;
+            if (sp.kind == K_REGULAR && bottleneck_bf16x3_supported(c, f))  // the opt-in arithmetic mode: 104 / 112 KB per layer
+                o.v[15] = ab.push(bf16x3::pack_layer(T(net, n + "proj_kernel").data(),
+                                                     T(net, n + (sp.asym ? "conv_kernel.0" : "conv_kernel")).data(),
+                                                     sp.asym ? T(net, n + "conv_kernel.1").data() : nullptr, sp.asym ? 10 : 9,
+                                                     T(net, n + "exp_kernel").data()));
             break;
         }
         case K_FINAL:
@@ -432,6 +441,7 @@ SSAL_API int ssal_enet_commit(ssal_enet *net, void *stream)
             L.res_w = L.kind == K_UP ? A + o.v[12] : nullptr;
             L.res_alpha = A + o.v[13];
             L.convT_stacked = L.kind == K_UP ? A + o.v[14] : nullptr;
+            L.bf3 = o.v[15] ? A + o.v[15] : nullptr;
             break;
         }
     }
@@ -516,9 +526,19 @@ bool up_fused(const DevLayer &L, int h, int w)
 }
 
 hipError_t run_regular(const DevLayer &L, const float *x, int n, int h, int w, float *y,
-                       const LayerTemps &T, hipStream_t s)
+                       const LayerTemps &T, hipStream_t s, int arith = SSAL_ARITH_F32)
 {
     const int C = L.cin, f = L.f;
+    if (arith == SSAL_ARITH_BF16X3 && L.bf3 && regular_fused(L, h, w)) {  // opt-in: split-operand bf16 MFMAs, NOT bit-identical
+        BnkArgs a;
+        memset(&a, 0, sizeof(a));
+        a.x = x; a.y = y;
+        a.wp = L.proj_w; a.ps = L.proj_scale; a.pt = L.proj_shift; a.pa = L.proj_alpha;
+        a.wc = L.conv_w; a.wc2 = L.asym ? L.conv_w1 : nullptr; a.cs = L.conv_scale; a.ct = L.conv_shift; a.ca = L.conv_alpha;
+        a.we = L.exp_w; a.es = L.exp_scale; a.et = L.exp_shift; a.ra = L.res_alpha;
+        a.N = n; a.H = h; a.W = w; a.dil = L.dil;
+        return launch_bottleneck_bf16x3(a, L.bf3, s);
+    }
     if (regular_fused(L, h, w))
         return launch_bottleneck_mfma(x, y, n, h, w, C, L.dil, L.proj_w, L.proj_scale, L.proj_shift,
                                       L.proj_alpha, L.conv_w, L.asym ? L.conv_w1 : nullptr,
@@ -669,7 +689,7 @@ int check_dims(const ssal_enet *net, int n, int h, int w)
 // 1_1..1_4 ping-pong s1a / s1b; 2_0: s1a -> s2a; 2_1..3_8 ping-pong s2a / s2b (ends in s2a); 4_0: s2a -> s1a; 4_1, 4_2
 // ping-pong; 5_0: s1a -> a0; 5_1: a0 -> a1.  V holds the buffers of the images this call works on.
 hipError_t run_layer_idx(const ssal_enet *net, int li, const void *x, bool x_is_u8, const NetWorkspace &V, int n, int h,
-                         int w, hipStream_t s)
+                         int w, hipStream_t s, int arith = SSAL_ARITH_F32)
 {
     const DevLayer &L = net->layers[li];
     // Initial + Bottleneck1_0 in one launch: Initial's output (a0; no endpoint) is never written
@@ -685,7 +705,7 @@ hipError_t run_layer_idx(const ssal_enet *net, int li, const void *x, bool x_is_
     if (li == 1) return run_down(L, V.a0, n, h / 2, w / 2, V.s1a, V.code1, V.T, s);
     if (li <= 5) return run_regular(L, (li - 2) % 2 == 0 ? V.s1a : V.s1b, n, h / 4, w / 4, (li - 2) % 2 == 0 ? V.s1b : V.s1a, V.T, s);
     if (li == 6) return run_down(L, V.s1a, n, h / 4, w / 4, V.s2a, V.code2, V.T, s);
-    if (li <= 22) return run_regular(L, (li - 7) % 2 == 0 ? V.s2a : V.s2b, n, h / 8, w / 8, (li - 7) % 2 == 0 ? V.s2b : V.s2a, V.T, s);
+    if (li <= 22) return run_regular(L, (li - 7) % 2 == 0 ? V.s2a : V.s2b, n, h / 8, w / 8, (li - 7) % 2 == 0 ? V.s2b : V.s2a, V.T, s, arith);
     if (li == 23) return run_up(L, V.s2a, n, h / 8, w / 8, V.s1a, V.code2, nullptr, V.T, s);
     if (li <= 25) return run_regular(L, li == 24 ? V.s1a : V.s1b, n, h / 4, w / 4, li == 24 ? V.s1b : V.s1a, V.T, s);
     if (li == 26) return run_up(L, V.s1a, n, h / 4, w / 4, V.a0, V.code1, nullptr, V.T, s);
@@ -699,6 +719,7 @@ struct FinalOut {
     float threshold;
     uint8_t *label, *mask;
     float *conf;
+    int arith = SSAL_ARITH_F32;  // arithmetic mode of the whole call (rides here: every run_net caller builds one)
 };
 
 // the ranking pass (no logits / label / mask / confidence output) evaluates Bottleneck5_1 inside the Final + score kernel:
@@ -769,7 +790,7 @@ hipError_t run_net(const ssal_enet *net, const void *x, bool x_is_u8, int n, int
         hipStream_t sg = g < 0 ? s : cs.side[g];
         if (li == 28) return run_final(net, Vg, fin, i0, ng, h, w, sg);
         if (li == 27 && fuse_5_1(net, fin)) return hipSuccess;
-        return run_layer_idx(net, li, (const char *)x + (size_t)i0 * h * w * net->c_in * xelt, x_is_u8, Vg, ng, h, w, sg);
+        return run_layer_idx(net, li, (const char *)x + (size_t)i0 * h * w * net->c_in * xelt, x_is_u8, Vg, ng, h, w, sg, fin.arith);
     };
     if (G == 1) {
         for (int li = 0; li < 29; ++li) HIP_RET(issue(li, -1));
@@ -801,18 +822,27 @@ SSAL_API int64_t ssal_enet_workspace_bytes(const ssal_enet *net, int n, int h, i
     return W.bytes + 256;
 }
 
+static int check_arith(int arithmetic)
+{
+    if (arithmetic != SSAL_ARITH_F32 && arithmetic != SSAL_ARITH_BF16X3)
+        return fail(SSAL_EINVAL, "arithmetic must be SSAL_ARITH_F32 (0) or SSAL_ARITH_BF16X3 (1), got %d", arithmetic);
+    return SSAL_OK;
+}
+
 static int forward_any(ssal_enet *net, const void *x_dev, bool x_is_u8, int n, int h, int w, float *logits_dev,
-                       void *ws_dev, int64_t ws_bytes, void *stream)
+                       void *ws_dev, int64_t ws_bytes, void *stream, int arith = SSAL_ARITH_F32)
 {
     int rc = check_dims(net, n, h, w);
     if (rc) return rc;
+    if ((rc = check_arith(arith))) return rc;
     if (!x_dev || !logits_dev || !ws_dev) return fail(SSAL_EINVAL, "NULL device pointer");
     NetWorkspace W = carve(net, ws_dev, ws_bytes, n, h, w);
     if (!W.ok) return fail(SSAL_ENOMEM, "workspace too small: need %lld bytes, got %lld",
                            (long long)W.bytes, (long long)ws_bytes);
     hipStream_t s = (hipStream_t)stream;
     // logits only: the score outputs of the fused kernel go to the scratch partial buffer
-    const FinalOut fin = {logits_dev, SSAL_MEASURE_CONFIDENCE, 0.0f, nullptr, nullptr, nullptr};
+    FinalOut fin = {logits_dev, SSAL_MEASURE_CONFIDENCE, 0.0f, nullptr, nullptr, nullptr};
+    fin.arith = arith;
     HIP_TRY(run_net(net, x_dev, x_is_u8, n, h, w, W, fin, s));
     return SSAL_OK;
 }
@@ -831,10 +861,11 @@ SSAL_API int ssal_enet_forward_nhwc_u8(ssal_enet *net, const uint8_t *x_dev, int
 
 static int score_any(ssal_enet *net, const void *x_dev, bool x_is_u8, int n, int h, int w, int measure,
                      float threshold, double *scores_dev, uint8_t *label_dev, uint8_t *mask_dev, float *conf_dev,
-                     void *ws_dev, int64_t ws_bytes, void *stream)
+                     void *ws_dev, int64_t ws_bytes, void *stream, int arith = SSAL_ARITH_F32)
 {
     int rc = check_dims(net, n, h, w);
     if (rc) return rc;
+    if ((rc = check_arith(arith))) return rc;
     if (measure < 0 || measure > 2)
         return fail(SSAL_ENOTIMPL, "Uncertainty function not implemented (measure=%d)", measure);
     if (!x_dev || !scores_dev || !ws_dev) return fail(SSAL_EINVAL, "NULL device pointer");
@@ -842,7 +873,8 @@ static int score_any(ssal_enet *net, const void *x_dev, bool x_is_u8, int n, int
     if (!W.ok) return fail(SSAL_ENOMEM, "workspace too small: need %lld bytes, got %lld",
                            (long long)W.bytes, (long long)ws_bytes);
     hipStream_t s = (hipStream_t)stream;
-    const FinalOut fin = {nullptr, measure, threshold, label_dev, mask_dev, conf_dev};
+    FinalOut fin = {nullptr, measure, threshold, label_dev, mask_dev, conf_dev};
+    fin.arith = arith;
     HIP_TRY(run_net(net, x_dev, x_is_u8, n, h, w, W, fin, s));
     HIP_TRY(launch_reduce_mean(W.partial, n, final_score_blocks(h / 2, w / 2), (double)h * (double)w,
                                scores_dev, s));
@@ -865,6 +897,21 @@ SSAL_API int ssal_enet_score_nhwc_u8(ssal_enet *net, const uint8_t *x_dev, int n
 {
     return score_any(net, x_dev, true, n, h, w, measure, threshold, scores_dev, label_dev, mask_dev, conf_dev,
                      ws_dev, ws_bytes, stream);
+}
+
+// ---- the same entry points with an explicit arithmetic mode (include/ssal_enet.h: SSAL_ARITH_*) ----
+SSAL_API int ssal_enet_forward_nhwc_arith(ssal_enet *net, const void *x_dev, int x_is_u8, int n, int h, int w, int arithmetic,
+                                          float *logits_dev, void *ws_dev, int64_t ws_bytes, void *stream)
+{
+    return forward_any(net, x_dev, x_is_u8 != 0, n, h, w, logits_dev, ws_dev, ws_bytes, stream, arithmetic);
+}
+
+SSAL_API int ssal_enet_score_nhwc_arith(ssal_enet *net, const void *x_dev, int x_is_u8, int n, int h, int w, int measure,
+                                        float threshold, int arithmetic, double *scores_dev, uint8_t *label_dev,
+                                        uint8_t *mask_dev, float *conf_dev, void *ws_dev, int64_t ws_bytes, void *stream)
+{
+    return score_any(net, x_dev, x_is_u8 != 0, n, h, w, measure, threshold, scores_dev, label_dev, mask_dev, conf_dev, ws_dev,
+                     ws_bytes, stream, arithmetic);
 }
 
 // byte offsets (into the workspace passed to forward/score) of the tensors behind
@@ -927,10 +974,29 @@ SSAL_API int64_t ssal_enet_layer_workspace_bytes(const ssal_enet *net, const cha
     return bytes;
 }
 
+static int run_layer_any(ssal_enet *net, const char *layer, const float *x_dev, int n, int h, int w, float *y_dev,
+                         int64_t *argmax_out_dev, const int64_t *argmax_in_dev, void *ws_dev, int64_t ws_bytes, void *stream,
+                         int arith);
+
 SSAL_API int ssal_enet_run_layer(ssal_enet *net, const char *layer, const float *x_dev, int n, int h,
                                  int w, float *y_dev, int64_t *argmax_out_dev,
                                  const int64_t *argmax_in_dev, void *ws_dev, int64_t ws_bytes,
                                  void *stream)
+{
+    return run_layer_any(net, layer, x_dev, n, h, w, y_dev, argmax_out_dev, argmax_in_dev, ws_dev, ws_bytes, stream, SSAL_ARITH_F32);
+}
+
+SSAL_API int ssal_enet_run_layer_arith(ssal_enet *net, const char *layer, const float *x_dev, int n, int h, int w, int arithmetic,
+                                       float *y_dev, int64_t *argmax_out_dev, const int64_t *argmax_in_dev, void *ws_dev,
+                                       int64_t ws_bytes, void *stream)
+{
+    if (int rc = check_arith(arithmetic)) return rc;
+    return run_layer_any(net, layer, x_dev, n, h, w, y_dev, argmax_out_dev, argmax_in_dev, ws_dev, ws_bytes, stream, arithmetic);
+}
+
+static int run_layer_any(ssal_enet *net, const char *layer, const float *x_dev, int n, int h, int w, float *y_dev,
+                         int64_t *argmax_out_dev, const int64_t *argmax_in_dev, void *ws_dev, int64_t ws_bytes, void *stream,
+                         int arith)
 {
     if (!net || !layer) return fail(SSAL_EINVAL, "NULL argument");
     if (!net->committed) return fail(SSAL_ESTATE, "ssal_enet_commit() has not been called");
@@ -960,7 +1026,7 @@ SSAL_API int ssal_enet_run_layer(ssal_enet *net, const char *layer, const float 
         HIP_TRY(launch_initial(x_dev, false, n, h, w, net->c_in, L.w, L.scale, L.shift, L.alpha, y_dev, s));
         break;
     case K_REGULAR:
-        HIP_TRY(run_regular(L, x_dev, n, h, w, y_dev, T, s));
+        HIP_TRY(run_regular(L, x_dev, n, h, w, y_dev, T, s, arith));
         break;
     case K_DOWN: {
         uint8_t *code = b.take<uint8_t>((int64_t)n * (h / 2) * (w / 2) * L.cin);

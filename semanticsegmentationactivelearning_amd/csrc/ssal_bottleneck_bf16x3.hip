@@ -1,0 +1,481 @@
+// ssal_bottleneck_bf16x3.hip -- OPT-IN arithmetic mode SSAL_ARITH_BF16X3 (include/ssal_enet.h) of the regular / dilated /
+// asymmetric 128-channel ENet bottleneck (enet_modules.py:526-599).  Never the default, never the bench headline.
+//
+// What it is.  The default kernels (ssal_bottleneck_mfma.hip) evaluate every convolution on v_mfma_f32_32x32x2_f32: exact
+// fp32 fmaf chains, bit-identical to the parity oracle, and bound by the fp32 matrix rate (155 TFLOP/s measured).  Here
+// every fp32 operand is split into three bf16 terms, x = x1 + x2 + x3 EXACTLY (three truncations cover the 24 significant
+// bits), and a K = 16 step of a 32x32 tile is SIX v_mfma_f32_32x32x16_bf16 -- x3w1, x2w2, x1w3, x2w1, x1w2, x1w1, small terms
+// first, every product exact, fp32 accumulation -- which drops only the O(2^-24) cross terms x2w3, x3w2, x3w3: the same
+// accuracy class as fp32 (tests/test_split_operand_cpu.py: 7.7e-6 against 5.9e-6 max logit error versus float64), 2.7x the
+// matrix rate with pre-split operands.  It is a DIFFERENT summation than the oracle's fmaf chains, so results are not
+// bit-identical to the default mode; its parity gate is north_star's own tolerance (confidence <= 1e-4, identical top-k,
+// pooling indices bit-identical: both pooling layers run in front of these layers and stay exact).
+//
+// How it is built for gfx950 (one workgroup = 4 waves = one 8 x 16 tile of ONE dilation-phase sub-image, as k_bottleneck_o4):
+//   kernels   pre-split and pre-packed per layer at commit (host): [chunk][term][lane] x 16 B, one buffer_load_b128 per term
+//   phase A   projection as D[co][pixel] (lane = pixel) of the 10 x 18 halo'd tile: 2 ring M-tiles (waves 0 / 1) + one centre
+//             M-tile per wave; input split in registers (32 and/sub + 12 v_perm per 8 values), 32 input registers in flight
+//   LDS       the projected tile P is stored ALREADY SPLIT: per halo pixel 3 terms x 32 bf16 (192 B + 16 B pad), written
+//             once per pixel as packed 8-byte stores -- so the convolution's 18 K-chunks read their B operand with three
+//             ds_read_b128 and no vector work at all (the round-4 probe re-split P at every tap: 9x the split work)
+//   phase B   3x3 conv D[co][pixel] -> BN + PReLU -> one swap per register pair + split -> expansion D[pixel][co] (lane = output
+//             channel) -> BN + residual (re-read as 128-byte rows) + PReLU -> 128-byte row stores.
+// Measured forms (profiles/r05_ab_bf16x3_forms.txt): keeping the centre input in registers as the residual (block input read
+// once, expansion as D[co][pixel], 16-byte stores of 4 channels per lane on a 512-byte stride; 196 VGPRs = 2 workgroups per CU)
+// 116-121 us per launch; the same store shape with the residual re-read 114-123 us; THIS form 83-94 us (exact fp32: 113-120):
+// what decides is the access shape of the epilogue, not the bytes.
+// Roofline: the six-product arithmetic of one launch (batch 8) needs ~25 us of bf16 matrix pipe; its HBM traffic -- input
+// 1.41x (halo) + residual re-read + output = ~440 MB -- 70 us at 6.3 TB/s: HBM-bound; measured 83-94 us = 4.7-5.3 TB/s.
+#include "ssal_internal.h"
+#include "ssal_mfma.h"
+#include "ssal_bottleneck_args.h"
+#include "ssal_bf16x3.h"
+#include "ssal_prof.h"
+
+namespace ssal {
+
+namespace {
+constexpr int F = 32, C = 128;
+constexpr int TW = 16, TH = 8;
+constexpr int PS = 208;  // bytes per P slot: 3 terms x 32 bf16 = 192 B, padded to 208 (16-byte aligned rows, 52-dword pitch)
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct Split3 {
+    uint4 t1, t2, t3;  // 8 values each: the leading bf16, the bf16 of the remainder, the bf16 of what remains after that
+};
+
+__device__ __forceinline__ unsigned pack_hi(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
+
+// x = h1 + h2 + h3 exactly; h1, h2 are fp32 values with 16 zero low bits, h3 fits 8 significant bits (its low 16 bits are 0)
+__device__ __forceinline__ void split1(float x, unsigned &h1, unsigned &h2, unsigned &h3)
+{
+    h1 = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(h1);
+    h2 = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(h2);
+    h3 = __float_as_uint(r2);
+}
+
+__device__ __forceinline__ Split3 split_pack8(const float (&v)[8])
+{
+    unsigned a[8], b[8], c[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) split1(v[k], a[k], b[k], c[k]);
+    Split3 s;
+    s.t1 = make_uint4(pack_hi(a[0], a[1]), pack_hi(a[2], a[3]), pack_hi(a[4], a[5]), pack_hi(a[6], a[7]));
+    s.t2 = make_uint4(pack_hi(b[0], b[1]), pack_hi(b[2], b[3]), pack_hi(b[4], b[5]), pack_hi(b[6], b[7]));
+    s.t3 = make_uint4(pack_hi(c[0], c[1]), pack_hi(c[2], c[3]), pack_hi(c[4], c[5]), pack_hi(c[6], c[7]));
+    return s;
+}
+
+__device__ __forceinline__ f32x16 mfma_bf(uint4 a, uint4 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// one K = 16 step: the six leading cross products, small terms first
+__device__ __forceinline__ f32x16 mfma6(const Split3 &a, const Split3 &b, f32x16 c)
+{
+    c = mfma_bf(a.t3, b.t1, c);
+    c = mfma_bf(a.t2, b.t2, c);
+    c = mfma_bf(a.t1, b.t3, c);
+    c = mfma_bf(a.t2, b.t1, c);
+    c = mfma_bf(a.t1, b.t2, c);
+    c = mfma_bf(a.t1, b.t1, c);
+    return c;
+}
+
+// packed kernel chunk `unit` (16-byte units, bf16x3::CHUNK_UNITS per chunk): [term][lane]
+__device__ __forceinline__ Split3 load_w(const rsrc_t &rs, int unit_off, int lane)
+{
+    Split3 s;
+    const unsigned lo = (unsigned)lane * 16u;
+    s.t1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, lo, (unit_off + 0) * 16, 0));
+    s.t2 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, lo, (unit_off + 64) * 16, 0));
+    s.t3 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, lo, (unit_off + 128) * 16, 0));
+    return s;
+}
+
+// the pre-split B operand of one K = 16 chunk from an LDS slot: term t at +64 t bytes, channels 16 c2 + 8 h .. + 7
+__device__ __forceinline__ Split3 load_p(const unsigned char *slot, int c2, int h)
+{
+    const unsigned char *p = slot + 32 * c2 + 16 * h;
+    Split3 s;
+    s.t1 = *reinterpret_cast<const uint4 *>(p);
+    s.t2 = *reinterpret_cast<const uint4 *>(p + 64);
+    s.t3 = *reinterpret_cast<const uint4 *>(p + 128);
+    return s;
+}
+
+// four consecutive channels (co0 .. co0 + 3) of one pixel -> the slot's three bf16 planes, 8 bytes each
+__device__ __forceinline__ void store_split4(unsigned char *slot, int co0, float v0, float v1, float v2, float v3)
+{
+    unsigned a[4], b[4], c[4];
+    split1(v0, a[0], b[0], c[0]);
+    split1(v1, a[1], b[1], c[1]);
+    split1(v2, a[2], b[2], c[2]);
+    split1(v3, a[3], b[3], c[3]);
+    unsigned char *p = slot + 2 * co0;
+    *reinterpret_cast<uint2 *>(p) = make_uint2(pack_hi(a[0], a[1]), pack_hi(a[2], a[3]));
+    *reinterpret_cast<uint2 *>(p + 64) = make_uint2(pack_hi(b[0], b[1]), pack_hi(b[2], b[3]));
+    *reinterpret_cast<uint2 *>(p + 128) = make_uint2(pack_hi(c[0], c[1]), pack_hi(c[2], c[3]));
+}
+
+struct Tile {
+    int n, py, px, ty0, tx0, Hp, Wp;
+    bool empty;
+};
+
+__device__ __forceinline__ Tile decode(const BnkArgs &a)
+{
+    Tile t;
+    const int d = a.dil;
+    int b = blockIdx.x;
+    t.empty = true;
+    if (a.xcd_chunk > 0) {  // XCD-aware order: workgroup b runs on XCD b % 8; every XCD gets a contiguous run of tiles
+        b = (b & 7) * a.xcd_chunk + (b >> 3);
+    }
+    if (b >= a.ntiles) return t;
+    const int tx = b % a.tiles_x; b /= a.tiles_x;
+    const int ty = b % a.tiles_y; b /= a.tiles_y;
+    t.px = b % d; b /= d;
+    t.py = b % d; b /= d;
+    t.n = b;
+    t.Hp = (a.H - t.py + d - 1) / d;
+    t.Wp = (a.W - t.px + d - 1) / d;
+    t.ty0 = ty * TH;
+    t.tx0 = tx * TW;
+    t.empty = (t.ty0 >= t.Hp) || (t.tx0 >= t.Wp);
+    return t;
+}
+
+// ---- 1x1 projection 128 -> 32 of ONE M-tile as D[co][pixel]: lane (j, h) owns the pixel whose halo'd-tile slot is q
+// (q < 0: no pixel), loads its channels 16 c + 8 h .. + 7 of every chunk c, and writes BN + PReLU of the result -- exact zeros outside the image: SAME padding applies to the PROJECTED
+// tensor -- pre-split into P.  HWPX = pixels per halo'd row, HALO = 1 (3x3) / 2 (5x1, 1x5).
+// Chunks 0..3 of the input are requested up front and chunk c + 4 when chunk c has been consumed (32 registers in flight).
+template <int HWPX, int HALO>
+__device__ __forceinline__ void project_tile(const BnkArgs &a, const Tile &t, const float *ximg, const rsrc_t &wrs, int q,
+                                             unsigned char *P, int lane, int h)
+{
+    float4 X[16];
+    const int d = a.dil;
+    const int hr = q / HWPX, hc = q - hr * HWPX;
+    const int pr = t.ty0 - HALO + hr, pc = t.tx0 - HALO + hc;
+    const bool valid = (q >= 0) && (pr >= 0) && (pr < t.Hp) && (pc >= 0) && (pc < t.Wp);
+    if (__ballot(valid) == 0ull) {  // wave-uniform: the whole M-tile lies outside the image
+        if (q >= 0) {
+#pragma unroll
+            for (int g = 0; g < 12; ++g) *reinterpret_cast<uint4 *>(P + q * PS + 16 * g) = make_uint4(0u, 0u, 0u, 0u);
+        }
+        return;
+    }
+    const float *xp = valid ? ximg + ((long)(t.py + pr * d) * a.W + (t.px + pc * d)) * C : ximg;
+    auto load_x = [&](int c) {
+        X[2 * c] = *reinterpret_cast<const float4 *>(xp + 16 * c + 8 * h);
+        X[2 * c + 1] = *reinterpret_cast<const float4 *>(xp + 16 * c + 8 * h + 4);
+    };
+#pragma unroll
+    for (int c = 0; c < 4; ++c) load_x(c);
+    f32x16 acc = {0};
+    Split3 wA = load_w(wrs, bf16x3::WP_OFF, lane), wB;  // packed kernel chunks one ahead (L2)
+#pragma unroll
+    for (int c = 0; c < 8; c += 2) {
+        wB = load_w(wrs, bf16x3::WP_OFF + (c + 1) * bf16x3::CHUNK_UNITS, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const float v[8] = {X[2 * c].x, X[2 * c].y, X[2 * c].z, X[2 * c].w, X[2 * c + 1].x, X[2 * c + 1].y,
+                                X[2 * c + 1].z, X[2 * c + 1].w};
+            acc = mfma6(wA, split_pack8(v), acc);  // D[co][pixel]: A = kernel (rows co), B = activations
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c < 4) { load_x(c + 4); load_x(c + 5); }
+        if (c + 2 < 8) wA = load_w(wrs, bf16x3::WP_OFF + (c + 2) * bf16x3::CHUNK_UNITS, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const float v[8] = {X[2 * c + 2].x, X[2 * c + 2].y, X[2 * c + 2].z, X[2 * c + 2].w, X[2 * c + 3].x, X[2 * c + 3].y,
+                                X[2 * c + 3].z, X[2 * c + 3].w};
+            acc = mfma6(wB, split_pack8(v), acc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // reg 4g + k = co 8g + 4h + k of the lane's pixel
+    const rsrc_t srs = make_rsrc(a.ps, F * 4), trs = make_rsrc(a.pt, F * 4), ars = make_rsrc(a.pa, F * 4);
+    if (q >= 0) {
+        unsigned char *slot = P + q * PS;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 s4 = bload4(srs, h * 16, g * 32), t4 = bload4(trs, h * 16, g * 32), a4 = bload4(ars, h * 16, g * 32);
+            const float v0 = valid ? prelu1(fmaf(acc[4 * g + 0], s4.x, t4.x), a4.x) : 0.0f;
+            const float v1 = valid ? prelu1(fmaf(acc[4 * g + 1], s4.y, t4.y), a4.y) : 0.0f;
+            const float v2 = valid ? prelu1(fmaf(acc[4 * g + 2], s4.z, t4.z), a4.z) : 0.0f;
+            const float v3 = valid ? prelu1(fmaf(acc[4 * g + 3], s4.w, t4.w), a4.w) : 0.0f;
+            store_split4(slot, 8 * g + 4 * h, v0, v1, v2, v3);
+        }
+    }
+}
+
+// BN + PReLU of a D[co][pixel] accumulator (reg 4g + k = channel 8g + 4h + k) -> the two pre-split operand chunks of the next
+// GEMM (lane (pixel j, h) holds ci = 16 c + 8 h + 0..7: the layout of an A operand with rows = pixels and of a B operand with
+// columns = pixels alike)
+__device__ __forceinline__ void bn_prelu_to_b(const f32x16 &acc, const rsrc_t &srs, const rsrc_t &trs, const rsrc_t &ars, int h,
+                                              Split3 (&qb)[2])
+{
+    float qv[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 s4 = bload4(srs, h * 16, g * 32), t4 = bload4(trs, h * 16, g * 32), a4 = bload4(ars, h * 16, g * 32);
+        qv[4 * g + 0] = prelu1(fmaf(acc[4 * g + 0], s4.x, t4.x), a4.x);
+        qv[4 * g + 1] = prelu1(fmaf(acc[4 * g + 1], s4.y, t4.y), a4.y);
+        qv[4 * g + 2] = prelu1(fmaf(acc[4 * g + 2], s4.z, t4.z), a4.z);
+        qv[4 * g + 3] = prelu1(fmaf(acc[4 * g + 3], s4.w, t4.w), a4.w);
+    }
+    // lane (pixel j, h) needs ci = 16 c + 8 h + 0..7: groups 2c and 2c + 1 exchange halves
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) swap32(qv[8 * cc + k], qv[8 * cc + 4 + k]);
+        const float v[8] = {qv[8 * cc + 0], qv[8 * cc + 1], qv[8 * cc + 2], qv[8 * cc + 3],
+                            qv[8 * cc + 4], qv[8 * cc + 5], qv[8 * cc + 6], qv[8 * cc + 7]};
+        qb[cc] = split_pack8(v);
+    }
+}
+
+// 1x1 expansion as D[pixel][co] (lane = output channel, registers = the M-tile's 32 pixels): 128-byte row stores and
+// row-wise residual re-reads, the access shape of the exact kernels' epilogue.  boff[i] = byte offset (inside the image, lane
+// channel folded in) of pixel row i of the M-tile, out-of-range for pixels outside the image (the hardware range check drops
+// their stores / answers their loads with 0).
+__device__ __forceinline__ void expand_store_rows(const BnkArgs &a, const rsrc_t &wrs, int we_off, const Split3 (&qa)[2],
+                                                  const rsrc_t &xrs, const rsrc_t &yrs, const unsigned (&boff)[16], int lane, int j)
+{
+    const rsrc_t esrs = make_rsrc(a.es, C * 4), etrs = make_rsrc(a.et, C * 4), rars = make_rsrc(a.ra, C * 4);
+    float rx[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) rx[i] = bload(xrs, boff[i], 0);
+    Split3 we0 = load_w(wrs, we_off, lane), we1 = load_w(wrs, we_off + bf16x3::CHUNK_UNITS, lane);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const float s1 = bload(esrs, j * 4, nt * 128), t1 = bload(etrs, j * 4, nt * 128), al = bload(rars, j * 4, nt * 128);
+        f32x16 e = {0};
+        e = mfma6(qa[0], we0, e);  // D[pixel][co]: A = Q (rows = pixels), B = kernel
+        e = mfma6(qa[1], we1, e);
+        if (nt < 3) {
+            we0 = load_w(wrs, we_off + (nt * 2 + 2) * bf16x3::CHUNK_UNITS, lane);
+            we1 = load_w(wrs, we_off + (nt * 2 + 3) * bf16x3::CHUNK_UNITS, lane);
+        }
+        float out[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) out[i] = prelu1(fmaf(e[i], s1, t1) + rx[i], al);
+        if (nt < 3) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) rx[i] = bload(xrs, boff[i], (nt + 1) * 128);  // next N-tile's residual rows, ahead of the stores
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, out[i]), yrs, boff[i], nt * 128, 0);
+    }
+}
+
+// byte offsets (inside image n, lane channel j folded in) of the 16 pixel rows of the M-tile that starts at tile pixel tp0
+// which this lane half holds in a D[pixel][co] accumulator; out of range for pixels outside the image
+__device__ __forceinline__ void row_offsets(const BnkArgs &a, const Tile &t, int tp0, int h, int j, unsigned (&boff)[16])
+{
+    constexpr unsigned kOOB = 0x80000000u;
+    const int d = a.dil;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int ti = tp0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        const int pr = t.ty0 + (ti >> 4), pc = t.tx0 + (ti & 15);
+        boff[i] = (pr < t.Hp && pc < t.Wp) ? (unsigned)((((t.py + pr * d) * a.W + (t.px + pc * d)) * C + j) * 4) : kOOB;
+    }
+}
+
+// ---- regular / dilated 3x3 bottleneck ------------------------------------------------------------------------------------
+constexpr int HWP3 = TW + 2;                   // 18
+constexpr int RING3 = 2 * HWP3 + 2 * TH;       // 52 ring pixels
+constexpr int PSLOTS3 = (TH + 2) * HWP3;       // 180
+
+// 103-120 VGPRs, 37.4 KB of LDS: four workgroups per CU
+__global__ __launch_bounds__(256, 4) void k_bottleneck_bf16x3(BnkArgs a, const uint4 *wpk)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char P[PSLOTS3 * PS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const Tile t = decode(a);
+    if (t.empty) return;  // whole workgroup: no barrier has been reached yet
+    const float *ximg = a.x + (long)t.n * a.H * a.W * C;
+    float *yimg = a.y + (long)t.n * a.H * a.W * C;
+    const rsrc_t wrs = make_rsrc(wpk, bf16x3::units(9) * 16);
+
+    auto q_ring = [&](int u) {  // halo'd-tile slot of ring pixel u: top row, bottom row, then (left, right) of rows 1..8
+        const int k = u - 2 * HWP3;
+        return u < HWP3 ? u
+                        : (u < 2 * HWP3 ? (TH + 1) * HWP3 + (u - HWP3)
+                                        : (u < RING3 ? (1 + (k >> 1)) * HWP3 + ((k & 1) ? HWP3 - 1 : 0) : -1));
+    };
+    if (wave < 2) project_tile<HWP3, 1>(a, t, ximg, wrs, q_ring(wave * 32 + j), P, lane, h);
+    const int tp = wave * 32 + j, tr_ = tp >> 4, tc = tp & 15;  // this lane's centre pixel: tile row tr_, column tc
+    project_tile<HWP3, 1>(a, t, ximg, wrs, (tr_ + 1) * HWP3 + tc + 1, P, lane, h);
+    __syncthreads();
+
+    // ---- phase B: 3x3 conv D[co][pixel], 18 K-chunks (tap, half), one chunk ahead ----
+    f32x16 acc = {0};
+    {
+        auto fetch = [&](int q, Split3 &w, Split3 &p) {
+            const int tap = q >> 1, c2 = q & 1, kh = tap / 3, kw = tap - 3 * kh;
+            w = load_w(wrs, bf16x3::WC_OFF + q * bf16x3::CHUNK_UNITS, lane);
+            p = load_p(P + ((tr_ + kh) * HWP3 + (tc + kw)) * PS, c2, h);
+        };
+        Split3 wA, wB, pA, pB;
+        fetch(0, wA, pA);
+#pragma unroll 1
+        for (int q = 0; q < 18; q += 2) {
+            fetch(q + 1, wB, pB);
+            __builtin_amdgcn_sched_barrier(0);
+            acc = mfma6(wA, pA, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 2 < 18) fetch(q + 2, wA, pA);
+            __builtin_amdgcn_sched_barrier(0);
+            acc = mfma6(wB, pB, acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    Split3 qa[2];
+    bn_prelu_to_b(acc, make_rsrc(a.cs, F * 4), make_rsrc(a.ct, F * 4), make_rsrc(a.ca, F * 4), h, qa);
+    unsigned boff[16];
+    row_offsets(a, t, wave * 32, h, j, boff);
+    const unsigned img_bytes = (unsigned)(a.H * a.W * C) * 4u;
+    expand_store_rows(a, wrs, bf16x3::we_off(9), qa, make_rsrc(ximg, img_bytes), make_rsrc(yimg, img_bytes), boff, lane, j);
+}
+
+// ---- asymmetric bottleneck: (5,1) then (1,5), no BN / activation in between (enet_modules.py:553-563), dilation 1 --------
+// P = the projected tile with a 2-pixel halo, 12 x 20 slots; R = the (5,1) result for the 8 x 20 pixels the (1,5) conv
+// reads, ALSO stored pre-split (it is the B operand of the second convolution).  R reuses P's slots: result row r is
+// written over halo'd row r + 2 ... which the (5,1) taps of rows r + 1, r + 2 (kh = 1, 0) still read -- so R has its own
+// 160 slots and the workgroup takes 83 KB of LDS: one workgroup per CU would starve the matrix pipe, hence the two halves
+// below (rows 0-3, then 4-7, R = 80 slots): 66.6 KB, two workgroups per CU.
+constexpr int HWP5 = TW + 4;                   // 20
+constexpr int PSLOTS5 = (TH + 4) * HWP5;       // 240
+constexpr int RSLOTS5 = 4 * HWP5;              // 80: the (5,1) result of one half (4 rows x 20 columns)
+
+__global__ __launch_bounds__(256, 2) void k_bottleneck_asym_bf16x3(BnkArgs a, const uint4 *wpk)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char P[PSLOTS5 * PS];
+    __shared__ __attribute__((aligned(16))) unsigned char R[96 * PS];  // 80 used; 3 M-tiles of 32 lanes write up to slot 95
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const Tile t = decode(a);
+    if (t.empty) return;
+    const float *ximg = a.x + (long)t.n * a.H * a.W * C;
+    float *yimg = a.y + (long)t.n * a.H * a.W * C;
+    const rsrc_t wrs = make_rsrc(wpk, bf16x3::units(10) * 16);
+
+    // ---- phase A: the 240 halo'd pixels = 112 ring pixels (4 M-tiles, 16 lanes idle) + 128 centre pixels (one M-tile per
+    // wave).  Ring order: rows 0, 1, 10, 11 (20 each), then the 2 + 2 side pixels of rows 2..9.
+    auto q_ring = [&](int u) {
+        if (u < 2 * HWP5) return u;
+        if (u < 4 * HWP5) return (TH + 2) * HWP5 + (u - 2 * HWP5);
+        const int k = u - 4 * HWP5;  // 0 .. 31: row 2 + (k >> 2), side pixel k & 3 -> columns 0, 1, 18, 19
+        return k < 32 ? (2 + (k >> 2)) * HWP5 + ((k & 3) < 2 ? (k & 3) : HWP5 - 4 + (k & 3)) : -1;
+    };
+    project_tile<HWP5, 2>(a, t, ximg, wrs, q_ring(wave * 32 + j), P, lane, h);
+    const int tp = wave * 32 + j, tr_ = tp >> 4, tc = tp & 15;
+    project_tile<HWP5, 2>(a, t, ximg, wrs, (tr_ + 2) * HWP5 + tc + 2, P, lane, h);
+    __syncthreads();
+
+    const unsigned img_bytes = (unsigned)(a.H * a.W * C) * 4u;
+    const rsrc_t xrs = make_rsrc(ximg, img_bytes), yrs = make_rsrc(yimg, img_bytes);
+    const rsrc_t srs = make_rsrc(a.cs, F * 4), trs = make_rsrc(a.ct, F * 4), ars = make_rsrc(a.ca, F * 4);
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        // (5,1) conv of rows 4 half .. 4 half + 3, all 20 columns: 80 result pixels = 3 M-tiles (waves 0..2; 16 lanes idle).
+        // Result pixel u = (r, c') reads P slots (4 half + r + kh) * 20 + c', kh = 0..4; no BN / activation; -> R[u], pre-split
+        if (wave < 3) {
+            const int u = wave * 32 + j;
+            const bool live = u < RSLOTS5;
+            const int ub = live ? u : 0;
+            f32x16 acc = {0};
+            auto fetch = [&](int q, Split3 &w, Split3 &p) {
+                const int kh = q >> 1, c2 = q & 1;
+                w = load_w(wrs, bf16x3::WC_OFF + q * bf16x3::CHUNK_UNITS, lane);
+                p = load_p(P + (4 * half * HWP5 + ub + kh * HWP5) * PS, c2, h);
+            };
+            Split3 wA, wB, pA, pB;
+            fetch(0, wA, pA);
+#pragma unroll 1
+            for (int q = 0; q < 10; q += 2) {
+                fetch(q + 1, wB, pB);
+                __builtin_amdgcn_sched_barrier(0);
+                acc = mfma6(wA, pA, acc);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q + 2 < 10) fetch(q + 2, wA, pA);
+                __builtin_amdgcn_sched_barrier(0);
+                acc = mfma6(wB, pB, acc);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            unsigned char *slot = R + u * PS;  // u < 96: inside R
+#pragma unroll
+            for (int g = 0; g < 4; ++g) store_split4(slot, 8 * g + 4 * h, acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+        }
+        __syncthreads();  // R of this half complete
+        // (1,5) conv + BN + PReLU + expansion of the half's 64 output pixels: waves 2 half, 2 half + 1 own them
+        if ((wave >> 1) == half) {
+            const int rr = tr_ - 4 * half;  // row inside the half
+            f32x16 acc = {0};
+            auto fetch = [&](int q, Split3 &w, Split3 &p) {
+                const int kw = q >> 1, c2 = q & 1;
+                w = load_w(wrs, bf16x3::WC_OFF + (10 + q) * bf16x3::CHUNK_UNITS, lane);
+                p = load_p(R + (rr * HWP5 + tc + kw) * PS, c2, h);
+            };
+            Split3 wA, wB, pA, pB;
+            fetch(0, wA, pA);
+#pragma unroll 1
+            for (int q = 0; q < 10; q += 2) {
+                fetch(q + 1, wB, pB);
+                __builtin_amdgcn_sched_barrier(0);
+                acc = mfma6(wA, pA, acc);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q + 2 < 10) fetch(q + 2, wA, pA);
+                __builtin_amdgcn_sched_barrier(0);
+                acc = mfma6(wB, pB, acc);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            Split3 qa[2];
+            bn_prelu_to_b(acc, srs, trs, ars, h, qa);
+            unsigned boff[16];
+            row_offsets(a, t, wave * 32, h, j, boff);
+            expand_store_rows(a, wrs, bf16x3::we_off(10), qa, xrs, yrs, boff, lane, j);
+        }
+        if (half == 0) __syncthreads();  // R is rewritten by the second half
+    }
+}
+}  // namespace
+
+bool bottleneck_bf16x3_supported(int Cin, int f) { return Cin == C && f == F; }
+
+hipError_t launch_bottleneck_bf16x3(const BnkArgs &a0, const void *packed, hipStream_t s)
+{
+    BnkArgs a = a0;
+    const bool asym = a.wc2 != nullptr;
+    if (a.dil < 1 || a.dil > 64 || !packed || (asym && a.dil != 1)) return hipErrorInvalidValue;
+    a.TH = TH;
+    const int Hp = (a.H + a.dil - 1) / a.dil, Wp = (a.W + a.dil - 1) / a.dil;  // largest phase sub-image
+    a.tiles_y = (Hp + TH - 1) / TH;
+    a.tiles_x = (Wp + TW - 1) / TW;
+    const long grid = (long)a.N * a.dil * a.dil * a.tiles_y * a.tiles_x;
+    if (grid <= 0 || grid > 0x3fffffffL || (long)a.H * a.W * C > (1L << 29)) return hipErrorInvalidValue;
+    a.ntiles = (int)grid;
+    a.xcd_chunk = knobs().bnk_xcd ? (int)((grid + 7) / 8) : 0;
+    const long launch_grid = a.xcd_chunk ? 8L * a.xcd_chunk : grid;
+    a.trace = nullptr;
+    const double pix = (double)a.N * a.H * a.W, taps = asym ? 10.0 : 9.0;
+    ProfScope prof(asym ? "k_bottleneck_asym_bf16x3" : "k_bottleneck_bf16x3", 2.0 * pix * (C * F + taps * F * F + F * C),
+                   4.0 * (2.0 * pix * C + C * F * 2.0 + taps * F * F), s);
+    if (asym)
+        hipLaunchKernelGGL(k_bottleneck_asym_bf16x3, dim3((unsigned)launch_grid), dim3(256), 0, s, a, (const uint4 *)packed);
+    else
+        hipLaunchKernelGGL(k_bottleneck_bf16x3, dim3((unsigned)launch_grid), dim3(256), 0, s, a, (const uint4 *)packed);
+    return hipGetLastError();
+}
+
+}  // namespace ssal

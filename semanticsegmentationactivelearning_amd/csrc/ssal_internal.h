@@ -90,6 +90,11 @@ hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W,
                                   const float *wc, const float *wc2 /* asym: (1,5) kernel, else NULL */,
                                   const float *cs, const float *ct, const float *ca, const float *we,
                                   const float *es, const float *et, const float *ra, hipStream_t s);
+// opt-in SSAL_ARITH_BF16X3 form of the 128-channel regular / dilated / asymmetric block (ssal_bottleneck_bf16x3.hip);
+// packed = the layer's kernels in ssal_bf16x3.h layout (a.wc2 != NULL selects the asymmetric kernel)
+struct BnkArgs;
+bool bottleneck_bf16x3_supported(int Cin, int f);
+hipError_t launch_bottleneck_bf16x3(const BnkArgs &a, const void *packed, hipStream_t s);
 // MFMA-fused downsample bottleneck 64 -> 128 / 16 -> 64 (writes the 2x2 window codes)
 bool downsample_mfma_supported(int Cin, int Cout);
 hipError_t launch_downsample_mfma(const float *x, float *y, uint8_t *code, int N, int H, int W,

@@ -159,7 +159,11 @@ class ENet(_lib.DeviceState):
         return x
 
     # ---- forward: ENet.call (reference :320-407) -------------------------------------------
-    def __call__(self, inputs, training):
+    def __call__(self, inputs, training, arithmetic="f32"):
+        """``arithmetic``: "f32" (default; exact fp32, bit-identical to the parity oracle -- the reference's arithmetic) or
+        the OPT-IN "bf16x3" (include/ssal_enet.h SSAL_ARITH_BF16X3: split-operand bf16 MFMAs in the 128-channel
+        bottlenecks; logits within ~1e-5, pooling indices bit-identical, not bit-identical logits)."""
+        arith = _lib.arithmetic_code(arithmetic)
         if training:
             raise NotImplementedError(
                 "training=True (spatial dropout + batch statistics) is outside the MI355X "
@@ -175,9 +179,13 @@ class ENet(_lib.DeviceState):
                 raise ValueError("bad input dims %s" % (tuple(x.shape),))
             ws = self._workspace(nbytes, x.device)
             logits = torch.empty((n, h, w, self.classes), dtype=torch.float32, device=x.device)
-            fwd = L.ssal_enet_forward_nhwc_u8 if x.dtype == torch.uint8 else L.ssal_enet_forward_nhwc
-            _lib.check(fwd(handle, _lib.dev_ptr(x), n, h, w, _lib.dev_ptr(logits),
-                           _lib.dev_ptr(ws), ws.numel(), _lib.stream_ptr()))
+            if arith:
+                _lib.check(L.ssal_enet_forward_nhwc_arith(handle, _lib.dev_ptr(x), int(x.dtype == torch.uint8), n, h, w, arith,
+                                                          _lib.dev_ptr(logits), _lib.dev_ptr(ws), ws.numel(), _lib.stream_ptr()))
+            else:
+                fwd = L.ssal_enet_forward_nhwc_u8 if x.dtype == torch.uint8 else L.ssal_enet_forward_nhwc
+                _lib.check(fwd(handle, _lib.dev_ptr(x), n, h, w, _lib.dev_ptr(logits),
+                               _lib.dev_ptr(ws), ws.numel(), _lib.stream_ptr()))
             self._note_call(ws, (n, h, w), "forward")
             self._record_endpoints(handle, logits, ws, n, h, w)
         # The reference appends one symbolic tensor per graph build (enet.py:405); this implementation is
@@ -220,13 +228,17 @@ class ENet(_lib.DeviceState):
 
     # ---- fused pool scoring (active_learning.py:229-263) -----------------------------------
     def score(self, inputs, measure="entropy", threshold=0.0, return_label=False,
-              return_mask=False, return_confidence=False, out=None):
+              return_mask=False, return_confidence=False, out=None, arithmetic="f32"):
         """forward(training=False) + softmax + acquisition measure + float64 per-image mean.
 
         Returns scores [N] float64 (device tensor); optionally a dict with the per-pixel
-        pseudo label (uint8), pseudo mask (uint8, conf >= threshold) and confidence (fp32)."""
+        pseudo label (uint8), pseudo mask (uint8, conf >= threshold) and confidence (fp32).
+        ``arithmetic="bf16x3"`` is the opt-in split-operand mode (see ``__call__``): per-pixel confidences within
+        north_star's 1e-4 of the exact path, per-image scores within 1e-6, the same top-k on the bench pool
+        (tests/test_gpu_bf16x3.py); the default "f32" is the reference's arithmetic."""
         if measure not in _lib.MEASURES:
             raise NotImplementedError("Uncertainty function not implemented.")
+        arith = _lib.arithmetic_code(arithmetic)
         torch = _lib.require_gpu()
         x = self._prepare(inputs, False)
         n, h, w, _ = x.shape
@@ -241,18 +253,24 @@ class ENet(_lib.DeviceState):
             label = torch.empty((n, h, w), dtype=torch.uint8, device=x.device) if return_label else None
             mask = torch.empty((n, h, w), dtype=torch.uint8, device=x.device) if return_mask else None
             conf = torch.empty((n, h, w), dtype=torch.float32, device=x.device) if return_confidence else None
-            score = L.ssal_enet_score_nhwc_u8 if x.dtype == torch.uint8 else L.ssal_enet_score_nhwc
-            _lib.check(score(
-                handle, _lib.dev_ptr(x), n, h, w, _lib.MEASURES[measure], float(threshold),
-                _lib.dev_ptr(scores, torch.float64, "scores"), _lib.dev_ptr(label), _lib.dev_ptr(mask),
-                _lib.dev_ptr(conf), _lib.dev_ptr(ws), ws.numel(), _lib.stream_ptr()))
+            if arith:
+                _lib.check(L.ssal_enet_score_nhwc_arith(
+                    handle, _lib.dev_ptr(x), int(x.dtype == torch.uint8), n, h, w, _lib.MEASURES[measure], float(threshold),
+                    arith, _lib.dev_ptr(scores, torch.float64, "scores"), _lib.dev_ptr(label), _lib.dev_ptr(mask),
+                    _lib.dev_ptr(conf), _lib.dev_ptr(ws), ws.numel(), _lib.stream_ptr()))
+            else:
+                score = L.ssal_enet_score_nhwc_u8 if x.dtype == torch.uint8 else L.ssal_enet_score_nhwc
+                _lib.check(score(
+                    handle, _lib.dev_ptr(x), n, h, w, _lib.MEASURES[measure], float(threshold),
+                    _lib.dev_ptr(scores, torch.float64, "scores"), _lib.dev_ptr(label), _lib.dev_ptr(mask),
+                    _lib.dev_ptr(conf), _lib.dev_ptr(ws), ws.numel(), _lib.stream_ptr()))
             self._note_call(ws, (n, h, w), "score")
         if return_label or return_mask or return_confidence:
             return scores, {"label": label, "mask": mask, "confidence": conf}
         return scores
 
     # ---- single layer (Layer.__call__) -----------------------------------------------------
-    def _run_layer(self, layer, x, argmax_in, want_argmax):
+    def _run_layer(self, layer, x, argmax_in, want_argmax, arithmetic="f32"):
         torch = _lib.require_gpu()
         if not self.built:
             raise RuntimeError("build the model (call it once, or .build(input_shape)) before "
@@ -276,7 +294,7 @@ class ENet(_lib.DeviceState):
                 if tuple(amax_in.shape) != (n, h, w, layer.output_channels):
                     raise ValueError("unpool_argmax must have shape %s (got %s)"
                                      % ((n, h, w, layer.output_channels), tuple(amax_in.shape)))
-            _lib.check(L.ssal_enet_run_layer(handle, name, _lib.dev_ptr(x), n, h, w, _lib.dev_ptr(y),
-                                             _lib.dev_ptr(amax_out), _lib.dev_ptr(amax_in),
-                                             _lib.dev_ptr(ws), ws.numel(), _lib.stream_ptr()))
+            _lib.check(L.ssal_enet_run_layer_arith(handle, name, _lib.dev_ptr(x), n, h, w, _lib.arithmetic_code(arithmetic),
+                                                   _lib.dev_ptr(y), _lib.dev_ptr(amax_out), _lib.dev_ptr(amax_in),
+                                                   _lib.dev_ptr(ws), ws.numel(), _lib.stream_ptr()))
         return (y, amax_out) if want_argmax else y

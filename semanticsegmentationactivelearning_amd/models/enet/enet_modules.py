@@ -133,7 +133,7 @@ class Layer:
     def abi_tensors(self):
         raise NotImplementedError
 
-    def _run(self, inputs, training, argmax_in=None, want_argmax=False):
+    def _run(self, inputs, training, argmax_in=None, want_argmax=False, arithmetic="f32"):
         if training:
             raise NotImplementedError(
                 "training=True (spatial dropout + batch statistics) is outside the MI355X "
@@ -146,7 +146,7 @@ class Layer:
             raise ValueError("inputs must be NHWC rank-4 (got shape %s)" % (tuple(x.shape),))
         if not self.built:
             self.build(tuple(x.shape))
-        return self._owner._run_layer(self, x, argmax_in, want_argmax)
+        return self._owner._run_layer(self, x, argmax_in, want_argmax, arithmetic)
 
     def output_shape(self, n, h, w):
         raise NotImplementedError
@@ -265,8 +265,8 @@ class Bottleneck(Layer):
     def output_shape(self, n, h, w):
         return (n, h, w, self.output_channels)
 
-    def __call__(self, inputs, training, **kwargs):
-        return self._run(inputs, training)
+    def __call__(self, inputs, training, arithmetic="f32", **kwargs):
+        return self._run(inputs, training, arithmetic=arithmetic)
 
 
 class BottleneckDownsample(Layer):

@@ -837,13 +837,25 @@ __global__ __launch_bounds__(256, 2) void k_downsample_mfma(DownArgs a)
     // ---- phase B: 3x3 conv -> expansion D[co][pixel] -> + pooled residual (registers) -> float4 stores ----
     const float *wel = WE + h * C + j;  // We[2s + h][nt*32 + j] = wel[2s*C + nt*32]
     const float *bnl = BNV + 4 * h;     // vectors of channels nt*32 + 8g + 4h .. +3
+    const rsrc_t yrs = make_rsrc(yimg, (unsigned)(Ho * Wo * C) * 4u);  // launcher: Ho * Wo * C < 2^29
 #pragma unroll
     for (int k = 0; k < MPW; ++k) {
         const int mt = wave + 4 * k;
         float qv[16];
         conv_tile_q<TW, 3, 3, HW2>(a, P, a.wc, mt, j, h, qv);
         if (k == 0) tr.mark(4);  // first conv done
-        float *yp = yimg + (opixk[k] >= 0 ? opixk[k] : 0) * C + 4 * h;
+        // Output stores.  The accumulator hands every lane (= pixel) four 16-byte pieces (g = 0..3) of its own 128-byte row
+        // of N-tile nt; stored as they stand, one instruction touches 32 rows with 32 bytes each.  quad_transpose4 moves
+        // piece g = q of pixel 4Q + kk into register kk of lane q of the quad: store kk of a quad (both lane halves) then
+        // carries one WHOLE 128-byte row -- the store shape of a row-major epilogue (profiles/r05_ab_quad_transposed_stores.txt).
+        unsigned yoq[4];  // byte offsets (inside the image) of this lane's piece (32 q + 16 h) in the rows of pixels 4Q + kk
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int t2 = mt * 32 + (j & ~3) + kk;
+            const int oy2 = ty0 + t2 / TW, ox2 = tx0 + t2 % TW;
+            yoq[kk] = (oy2 < Ho && ox2 < Wo) ? (unsigned)((oy2 * Wo + ox2) * (C * 4) + 32 * (j & 3) + 16 * h) : 0x80000000u;
+        }
+        float4 ov[4];
         auto chain = [&](int nt, int s, f32x16 e) { return mfma32(wel[2 * s * C + nt * 32], qv[ord(s)], e); };
         auto epilogue = [&](int nt, int g, const f32x16 &e) {
             const float4 s4 = *reinterpret_cast<const float4 *>(bnl + nt * 32 + 8 * g);
@@ -855,7 +867,13 @@ __global__ __launch_bounds__(256, 2) void k_downsample_mfma(DownArgs a)
             o.y = prelu1(fmaf(e[4 * g + 1], s4.y, t4.y) + x4.y, a4.y);
             o.z = prelu1(fmaf(e[4 * g + 2], s4.z, t4.z) + x4.z, a4.z);
             o.w = prelu1(fmaf(e[4 * g + 3], s4.w, t4.w) + x4.w, a4.w);
-            if (opixk[k] >= 0) *reinterpret_cast<float4 *>(yp + nt * 32 + 8 * g) = o;
+            ov[g] = o;
+            if (g == 3) {
+                quad_transpose4(ov[0], ov[1], ov[2], ov[3], lane);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov[kk]), yrs, yoq[kk], nt * 128, 0);
+            }
         };
         f32x16 e0 = {0}, e1 = {0};
 #pragma unroll
@@ -1054,6 +1072,7 @@ __global__ __launch_bounds__(256, 2) void k_upsample_mfma(UpArgs a)
     // ---- phase B: transposed conv (2 stacked accumulators) -> expansion per parity class -> unpool-gated
     // residual -> float4 stores ----------------------------------------------------------------------------
     const rsrc_t wsrs = make_rsrc(a.ws, 6 * F * 32 * 4);
+    const rsrc_t yrs = make_rsrc(yimg, (unsigned)(4 * a.H * a.W * CUP) * 4u);  // launcher: 4 * H * W * 64 < 2^29
     const float *bnl = BNV + 4 * h;
 #pragma unroll
     for (int k = 0; k < MPW; ++k) {
@@ -1133,9 +1152,15 @@ __global__ __launch_bounds__(256, 2) void k_upsample_mfma(UpArgs a)
         }
         // expansion per (parity class, N-tile): D[co][pixel]; the chain of combination m+1 is issued
         // interleaved with the epilogue of combination m
-        const bool ok = ipixk[k] >= 0;
-        const int iy = ty0 + r, ix = tx0 + c;
-        float *yq = yimg + (ok ? ((long)(2 * iy) * (2 * a.W) + 2 * ix) * CUP : 0) + 4 * h;
+        // quad-transposed stores (see k_downsample_mfma): byte offsets of this lane's piece (32 q + 16 h) in the output rows
+        // that belong to the INPUT pixels 4Q + kk of its quad (class (0, 0); the class / N-tile displacement is wave-uniform)
+        unsigned yoq[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int t2 = mt * 32 + (j & ~3) + kk;
+            const int iy2 = ty0 + t2 / TW, ix2 = tx0 + t2 % TW;
+            yoq[kk] = (iy2 < a.H && ix2 < a.W) ? (unsigned)(((2 * iy2) * (2 * a.W) + 2 * ix2) * (CUP * 4) + 32 * (j & 3) + 16 * h) : 0x80000000u;
+        }
         auto chain = [&](int m, f32x16 e) {  // m = cls * 2 + nt
             const int cls = m >> 1, nt = m & 1;
 #pragma unroll
@@ -1147,7 +1172,8 @@ __global__ __launch_bounds__(256, 2) void k_upsample_mfma(UpArgs a)
         };
         auto epilogue = [&](int m, const f32x16 &e) {
             const int cls = m >> 1, nt = m & 1;
-            float *yp = yq + ((cls >> 1) * (2 * a.W) + (cls & 1)) * CUP + nt * 32;
+            const unsigned soff = (unsigned)((((cls >> 1) * (2 * a.W) + (cls & 1)) * CUP + nt * 32) * 4);
+            float4 ov[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 // keep the three LDS vector reads here: hoisted out of the class loop (they do not depend on
@@ -1163,8 +1189,12 @@ __global__ __launch_bounds__(256, 2) void k_upsample_mfma(UpArgs a)
                 o.y = prelu1(fmaf(e[4 * g + 1], s4.y, t4.y) + (((cd >> 8) & 0xFFu) == (unsigned)cls ? rs[4 * g + 1] : 0.0f), a4.y);
                 o.z = prelu1(fmaf(e[4 * g + 2], s4.z, t4.z) + (((cd >> 16) & 0xFFu) == (unsigned)cls ? rs[4 * g + 2] : 0.0f), a4.z);
                 o.w = prelu1(fmaf(e[4 * g + 3], s4.w, t4.w) + (((cd >> 24) & 0xFFu) == (unsigned)cls ? rs[4 * g + 3] : 0.0f), a4.w);
-                if (ok) *reinterpret_cast<float4 *>(yp + 8 * g) = o;
+                ov[g] = o;
             }
+            quad_transpose4(ov[0], ov[1], ov[2], ov[3], lane);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov[kk]), yrs, yoq[kk], soff, 0);
         };
         f32x16 e0 = chain(0, (f32x16){0}), e1;
 #pragma unroll

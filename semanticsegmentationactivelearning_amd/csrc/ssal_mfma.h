@@ -45,6 +45,39 @@ __device__ __forceinline__ void transpose4(float &r0, float &r1, float &r2, floa
     swap16(r2, r3);  // r2 = [8 9 10 11], r3 = [12 13 14 15]
 }
 
+// 4x4 transpose of a register quadruple across the four lanes of a QUAD (lanes 4Q .. 4Q + 3): after the call r[k] of lane
+// q (= lane & 3) holds what r[q] of lane 4Q + k held.  Two butterfly stages (lane bit <-> register bit), each one
+// v_cndmask to pick what is sent, one DPP quad_perm move, two v_cndmask to place what arrives: 16 vector instructions.
+// Use: a D[co][pixel] accumulator gives every lane (= pixel) four 16-byte pieces of its own 128-byte output row; stored as
+// they stand, one store instruction touches 32 rows with 32 bytes each.  Transposed over the quad, store k of a quad's
+// lanes carries the four pieces of ONE pixel (pixel 4Q + k): with both lane halves that is the whole 128-byte row per
+// instruction and quad -- the store shape of a row-major epilogue, without leaving the registers.
+__device__ __forceinline__ float dpp_quad_xor1(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float dpp_quad_xor2(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
+}
+__device__ __forceinline__ void quad_transpose4(float &r0, float &r1, float &r2, float &r3, int lane)
+{
+    const bool b0 = lane & 1, b1 = lane & 2;
+    const float s01 = dpp_quad_xor1(b0 ? r0 : r1), s23 = dpp_quad_xor1(b0 ? r2 : r3);
+    r0 = b0 ? s01 : r0; r1 = b0 ? r1 : s01;
+    r2 = b0 ? s23 : r2; r3 = b0 ? r3 : s23;
+    const float s02 = dpp_quad_xor2(b1 ? r0 : r2), s13 = dpp_quad_xor2(b1 ? r1 : r3);
+    r0 = b1 ? s02 : r0; r2 = b1 ? r2 : s02;
+    r1 = b1 ? s13 : r1; r3 = b1 ? r3 : s13;
+}
+__device__ __forceinline__ void quad_transpose4(float4 &a, float4 &b, float4 &c, float4 &d, int lane)
+{
+    quad_transpose4(a.x, b.x, c.x, d.x, lane);
+    quad_transpose4(a.y, b.y, c.y, d.y, lane);
+    quad_transpose4(a.z, b.z, c.z, d.z, lane);
+    quad_transpose4(a.w, b.w, c.w, d.w, lane);
+}
+
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c)
 {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);

@@ -349,19 +349,17 @@ __global__ __launch_bounds__(256, 4) void k_bottleneck_bf16x3(BnkArgs a, const u
 }
 
 // ---- asymmetric bottleneck: (5,1) then (1,5), no BN / activation in between (enet_modules.py:553-563), dilation 1 --------
-// P = the projected tile with a 2-pixel halo, 12 x 20 slots; R = the (5,1) result for the 8 x 20 pixels the (1,5) conv
-// reads, ALSO stored pre-split (it is the B operand of the second convolution).  R reuses P's slots: result row r is
-// written over halo'd row r + 2 ... which the (5,1) taps of rows r + 1, r + 2 (kh = 1, 0) still read -- so R has its own
-// 160 slots and the workgroup takes 83 KB of LDS: one workgroup per CU would starve the matrix pipe, hence the two halves
-// below (rows 0-3, then 4-7, R = 80 slots): 66.6 KB, two workgroups per CU.
+// P = the projected tile with a 2-pixel halo, 12 x 20 slots.  R = the (5,1) result for the 8 x 20 pixels the (1,5) conv
+// reads, ALSO pre-split (it is the B operand of the second convolution).  R has no LDS of its own: the (5,1) pass of the
+// whole tile (160 result pixels = exactly 5 M-tiles; wave 0 takes two) keeps its results in accumulator registers across a
+// barrier -- behind which every read of P is over -- and then writes them over P's rows 0..7.  49.9 KB of LDS, three
+// workgroups per CU (the first version: R in 20 KB of its own, the tile in two halves of 3 + 2 busy waves: 130 us).
 constexpr int HWP5 = TW + 4;                   // 20
 constexpr int PSLOTS5 = (TH + 4) * HWP5;       // 240
-constexpr int RSLOTS5 = 4 * HWP5;              // 80: the (5,1) result of one half (4 rows x 20 columns)
 
-__global__ __launch_bounds__(256, 2) void k_bottleneck_asym_bf16x3(BnkArgs a, const uint4 *wpk)
+__global__ __launch_bounds__(256, 3) void k_bottleneck_asym_bf16x3(BnkArgs a, const uint4 *wpk)
 {
     __shared__ __attribute__((aligned(16))) unsigned char P[PSLOTS5 * PS];
-    __shared__ __attribute__((aligned(16))) unsigned char R[96 * PS];  // 80 used; 3 M-tiles of 32 lanes write up to slot 95
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const Tile t = decode(a);
@@ -383,71 +381,70 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck_asym_bf16x3(BnkArgs a, co
     project_tile<HWP5, 2>(a, t, ximg, wrs, (tr_ + 2) * HWP5 + tc + 2, P, lane, h);
     __syncthreads();
 
-    const unsigned img_bytes = (unsigned)(a.H * a.W * C) * 4u;
-    const rsrc_t xrs = make_rsrc(ximg, img_bytes), yrs = make_rsrc(yimg, img_bytes);
-    const rsrc_t srs = make_rsrc(a.cs, F * 4), trs = make_rsrc(a.ct, F * 4), ars = make_rsrc(a.ca, F * 4);
+    // ---- (5,1) conv, no BN / activation: result pixel u = (r, c') of the 8 x 20 grid reads P slots u + 20 kh, kh = 0..4
+    auto conv51 = [&](int u) {
+        f32x16 acc = {0};
+        auto fetch = [&](int q, Split3 &w, Split3 &p) {
+            const int kh = q >> 1, c2 = q & 1;
+            w = load_w(wrs, bf16x3::WC_OFF + q * bf16x3::CHUNK_UNITS, lane);
+            p = load_p(P + (u + kh * HWP5) * PS, c2, h);
+        };
+        Split3 wA, wB, pA, pB;
+        fetch(0, wA, pA);
 #pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-        // (5,1) conv of rows 4 half .. 4 half + 3, all 20 columns: 80 result pixels = 3 M-tiles (waves 0..2; 16 lanes idle).
-        // Result pixel u = (r, c') reads P slots (4 half + r + kh) * 20 + c', kh = 0..4; no BN / activation; -> R[u], pre-split
-        if (wave < 3) {
-            const int u = wave * 32 + j;
-            const bool live = u < RSLOTS5;
-            const int ub = live ? u : 0;
-            f32x16 acc = {0};
-            auto fetch = [&](int q, Split3 &w, Split3 &p) {
-                const int kh = q >> 1, c2 = q & 1;
-                w = load_w(wrs, bf16x3::WC_OFF + q * bf16x3::CHUNK_UNITS, lane);
-                p = load_p(P + (4 * half * HWP5 + ub + kh * HWP5) * PS, c2, h);
-            };
-            Split3 wA, wB, pA, pB;
-            fetch(0, wA, pA);
-#pragma unroll 1
-            for (int q = 0; q < 10; q += 2) {
-                fetch(q + 1, wB, pB);
-                __builtin_amdgcn_sched_barrier(0);
-                acc = mfma6(wA, pA, acc);
-                __builtin_amdgcn_sched_barrier(0);
-                if (q + 2 < 10) fetch(q + 2, wA, pA);
-                __builtin_amdgcn_sched_barrier(0);
-                acc = mfma6(wB, pB, acc);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            unsigned char *slot = R + u * PS;  // u < 96: inside R
+        for (int q = 0; q < 10; q += 2) {
+            fetch(q + 1, wB, pB);
+            __builtin_amdgcn_sched_barrier(0);
+            acc = mfma6(wA, pA, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 2 < 10) fetch(q + 2, wA, pA);
+            __builtin_amdgcn_sched_barrier(0);
+            acc = mfma6(wB, pB, acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return acc;
+    };
+    const f32x16 r0 = conv51(wave * 32 + j);
+    f32x16 r1 = {0};
+    if (wave == 0) r1 = conv51(128 + j);  // the fifth M-tile (wave-uniform)
+    __syncthreads();  // nobody reads the projected rows any more
+    auto store_r = [&](const f32x16 &acc, int u) {
+        unsigned char *slot = P + u * PS;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) store_split4(slot, 8 * g + 4 * h, acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
-        }
-        __syncthreads();  // R of this half complete
-        // (1,5) conv + BN + PReLU + expansion of the half's 64 output pixels: waves 2 half, 2 half + 1 own them
-        if ((wave >> 1) == half) {
-            const int rr = tr_ - 4 * half;  // row inside the half
-            f32x16 acc = {0};
-            auto fetch = [&](int q, Split3 &w, Split3 &p) {
-                const int kw = q >> 1, c2 = q & 1;
-                w = load_w(wrs, bf16x3::WC_OFF + (10 + q) * bf16x3::CHUNK_UNITS, lane);
-                p = load_p(R + (rr * HWP5 + tc + kw) * PS, c2, h);
-            };
-            Split3 wA, wB, pA, pB;
-            fetch(0, wA, pA);
+        for (int g = 0; g < 4; ++g) store_split4(slot, 8 * g + 4 * h, acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+    };
+    store_r(r0, wave * 32 + j);
+    if (wave == 0) store_r(r1, 128 + j);
+    __syncthreads();  // R complete (slots 0 .. 159)
+
+    // ---- (1,5) conv + BN + PReLU + expansion: wave w owns tile rows 2w, 2w + 1
+    f32x16 acc = {0};
+    {
+        auto fetch = [&](int q, Split3 &w, Split3 &p) {
+            const int kw = q >> 1, c2 = q & 1;
+            w = load_w(wrs, bf16x3::WC_OFF + (10 + q) * bf16x3::CHUNK_UNITS, lane);
+            p = load_p(P + (tr_ * HWP5 + tc + kw) * PS, c2, h);
+        };
+        Split3 wA, wB, pA, pB;
+        fetch(0, wA, pA);
 #pragma unroll 1
-            for (int q = 0; q < 10; q += 2) {
-                fetch(q + 1, wB, pB);
-                __builtin_amdgcn_sched_barrier(0);
-                acc = mfma6(wA, pA, acc);
-                __builtin_amdgcn_sched_barrier(0);
-                if (q + 2 < 10) fetch(q + 2, wA, pA);
-                __builtin_amdgcn_sched_barrier(0);
-                acc = mfma6(wB, pB, acc);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            Split3 qa[2];
-            bn_prelu_to_b(acc, srs, trs, ars, h, qa);
-            unsigned boff[16];
-            row_offsets(a, t, wave * 32, h, j, boff);
-            expand_store_rows(a, wrs, bf16x3::we_off(10), qa, xrs, yrs, boff, lane, j);
+        for (int q = 0; q < 10; q += 2) {
+            fetch(q + 1, wB, pB);
+            __builtin_amdgcn_sched_barrier(0);
+            acc = mfma6(wA, pA, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 2 < 10) fetch(q + 2, wA, pA);
+            __builtin_amdgcn_sched_barrier(0);
+            acc = mfma6(wB, pB, acc);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (half == 0) __syncthreads();  // R is rewritten by the second half
     }
+    Split3 qa[2];
+    bn_prelu_to_b(acc, make_rsrc(a.cs, F * 4), make_rsrc(a.ct, F * 4), make_rsrc(a.ca, F * 4), h, qa);
+    unsigned boff[16];
+    row_offsets(a, t, wave * 32, h, j, boff);
+    const unsigned img_bytes = (unsigned)(a.H * a.W * C) * 4u;
+    expand_store_rows(a, wrs, bf16x3::we_off(10), qa, make_rsrc(ximg, img_bytes), make_rsrc(yimg, img_bytes), boff, lane, j);
 }
 }  // namespace
 

@@ -2,9 +2,9 @@
 (tracked).  Usage: python tools/collect_profiles.py [round=r02]"""
 import glob, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = sys.argv[1] if len(sys.argv) > 1 else "r04"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r05"
 SRC, DST = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-for model in ("enet", "icnet"):
+for model in ("enet", "icnet", "enet_bf16x3"):
     fs = glob.glob(os.path.join(SRC, "prof_final_%s" % model, "runc", "*_kernel_stats.csv"))
     if fs:
         # keep the kernel rows (drop torch helper kernels' very long names by truncating the name column)

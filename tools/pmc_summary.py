@@ -18,6 +18,8 @@ def short(name):
     n = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("ssal::", "")
     if n.startswith("k_front2"):  # k_front2<3, float, 2> -> k_front2<s2> (last template argument = stride of the second convolution)
         return "k_front2<s%s>" % n.rstrip(">").split(",")[-1].strip()
+    if n.startswith("k_bottleneck_bf16x3") or n.startswith("k_bottleneck_asym_bf16x3"):
+        return n.split("<")[0]
     if n.startswith("k_bottleneck16") or n.startswith("k_bottleneck_mfma"):
         return n.replace(" ", "")
     if n.startswith("k_final_score"):  # k_final_score<19, false, true> = Bottleneck5_1 evaluated inside (bench: "k_final_score<fused 5_1>")

@@ -13,4 +13,7 @@ for M in enet icnet; do
   timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_final_${M}_groups2 -- python3 bench.py --model $M --steps 40 --warmup 2 --no-cpu-baseline --no-secondary --no-roofline > $OUT/rocprof_final_${M}_groups2.log 2>&1; rc=$?; echo "rocprof $M groups2 rc=$rc"; [ $rc -ge 124 ] && exit $rc
   bash tools/gpu_pmc.sh $M || exit $?
 done
+# the opt-in bf16x3 kernels (never the headline): kernel stats + PMC of a run whose main leg scores in that mode
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_final_enet_bf16x3 -- python3 bench.py --arithmetic bf16x3 --steps 40 --warmup 2 --no-cpu-baseline --no-secondary --no-roofline --knob img_groups=1 --allow-nondefault-knobs > $OUT/rocprof_final_enet_bf16x3.log 2>&1; rc=$?; echo "rocprof enet bf16x3 rc=$rc"; [ $rc -ge 124 ] && exit $rc
+EXTRA="--arithmetic bf16x3" bash tools/gpu_pmc.sh enet enet_bf16x3 || exit $?
 tail -c 400 $OUT/bench_enet_full.json; tail -c 400 $OUT/bench_icnet.json

@@ -181,6 +181,48 @@ __device__ __forceinline__ void conv5x1_to_lds(const BnkArgs &a, const float *P,
     }
 }
 
+// one M-tile of the (5,1) result (pixels u0 .. u0 + 31 of the row-major 8 x HWP result grid) as an accumulator: rows =
+// pixels (registers), cols = co (lanes); taps one ahead as in conv5x1_to_lds
+template <int TW>
+__device__ __forceinline__ f32x16 conv5x1_tile(const BnkArgs &a, const float *P, int u0, int j, int h)
+{
+    constexpr int HWP = TW + 4;
+    const rsrc_t wrs = make_rsrc(a.wc, 5 * F * F * 4);
+    const unsigned lo = (unsigned)(h * 32 + j) * 4u;
+    const int u = u0 + j;
+    f32x16 acc = {0};
+    float wA[16], wB[16];
+    float2 pA[8], pB[8];
+    auto load_tap = [&](int kh, float (&w)[16], float2 (&pv)[8]) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) w[k] = bload(wrs, lo, kh * (F * F * 4) + k * 256);  // W0[kh][2k + h][j]
+        const float *pq = P + (u + kh * HWP) * PSTR;
+#pragma unroll
+        for (int sq = 0; sq < 8; ++sq) pv[sq] = *reinterpret_cast<const float2 *>(pq + kperm_rd(sq, h));
+    };
+    auto run_tap = [&](const float (&w)[16], const float2 (&pv)[8]) {
+#pragma unroll
+        for (int sq = 0; sq < 8; ++sq) {
+            acc = mfma32(pv[sq].x, w[2 * sq], acc);
+            acc = mfma32(pv[sq].y, w[2 * sq + 1], acc);
+        }
+    };
+    load_tap(0, wA, pA);
+#pragma unroll 1
+    for (int kh = 0; kh + 1 < 5; kh += 2) {
+        load_tap(kh + 1, wB, pB);
+        __builtin_amdgcn_sched_barrier(0);
+        run_tap(wA, pA);
+        __builtin_amdgcn_sched_barrier(0);
+        load_tap(kh + 2, wA, pA);
+        __builtin_amdgcn_sched_barrier(0);
+        run_tap(wB, pB);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    run_tap(wA, pA);
+    return acc;
+}
+
 // ---- KH x KW conv (F -> F) over an LDS tensor S (row stride SW pixels) for one 32-pixel M-tile,
 // + BN + PReLU; returns the result as the A operand of the following expansion GEMM:
 // qv[ord(s)] of lane (pixel j, half h) = Q[pixel][ci = 2s + h].
@@ -655,6 +697,38 @@ __global__ __launch_bounds__(256, 2) void k_bottleneck_mfma_asym(BnkArgs a)
 #endif
     tr.mark(7);
     tr.flush(a.trace, lane, wave);
+}
+
+// The asymmetric block on 8 x 16 tiles at THREE workgroups per CU (round 5; knob asym_tw16).  The (5,1) result R has no LDS
+// of its own: the (5,1) pass of the whole tile (8 x 20 = 160 result pixels = exactly 5 M-tiles, wave 0 takes two) keeps its
+// results in accumulator registers across a barrier, behind which no wave reads the projected rows any more, and writes them
+// over P's rows 0..7; the (1,5) convolution + expansion then runs one M-tile per wave.  P = 12 x 20 = 240 rows: 34.8 KB.
+constexpr int PROWS_ASYM16 = 256;  // 240 halo'd pixels, rounded up to whole M-tiles
+__global__ __launch_bounds__(256, 3) void k_bottleneck_mfma_asym16x(BnkArgs a)
+{
+    constexpr int TW = 16, HWP = TW + 4;
+    __shared__ float P[PROWS_ASYM16 * PSTR];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const TileId t = decode_tile<TW>(a);
+    if (t.empty) return;
+    const float *ximg = a.x + (long)t.n * a.H * a.W * C;
+    float *yimg = a.y + (long)t.n * a.H * a.W * C;
+    PhaseTrace tr;
+    proj_to_lds<TW, 2>(a, ximg, P, t.TH, t.ty0, t.tx0, t.py, t.px, t.Hp, t.Wp, wave, j, h, PROWS_ASYM16);
+    __syncthreads();  // P complete
+    const f32x16 r0 = conv5x1_tile<TW>(a, P, wave * 32, j, h);
+    f32x16 r1 = {0};
+    if (wave == 0) r1 = conv5x1_tile<TW>(a, P, 128, j, h);  // the fifth M-tile (wave-uniform)
+    __syncthreads();  // nobody reads the projected rows any more
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int ri = (i & 3) + 8 * (i >> 2) + 4 * h;
+        P[(wave * 32 + ri) * PSTR + kperm(j)] = r0[i];
+        if (wave == 0) P[(128 + ri) * PSTR + kperm(j)] = r1[i];
+    }
+    __syncthreads();  // R complete: result pixel (r, c') in row r * HWP + c'
+    conv_exp_store<TW, 1, 5, HWP>(a, ximg, yimg, P, a.wc2, 8, t.ty0, t.tx0, t.py, t.px, t.Hp, t.Wp, wave, j, h, tr);
 }
 
 // =================================================================================================
@@ -1235,6 +1309,7 @@ Knobs &knobs()
         q.bnk_tw = 0;
         q.bnk_o4 = 2;
         q.bnk_xcd = 1;
+        q.asym_tw16 = ASYM_TW16_DEFAULT;
         q.img_groups = 2;
         q.img_span = 4;
         q.fuse_ends = 3;
@@ -1384,7 +1459,8 @@ hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W,
     // 8x16 tiles at four workgroups per CU (k_bottleneck_o4): bnk_o4 = 1 everywhere (experiment), 2 = only where the phase
     // sub-image is at most 16 pixels wide, i.e. where 8x16 tiles are used anyway (the dilation-16 layers at 128 x 256)
     const bool o4 = !asym && Cin == C && (kn.bnk_o4 == 1 || (kn.bnk_o4 == 2 && Wp <= 16));
-    const bool wide = Wp > 16 && kn.bnk_tw != 16 && !o4;
+    const bool asym16x = asym && kn.asym_tw16 != 0;  // 8 x 16 tiles, three workgroups per CU, R written over P
+    const bool wide = Wp > 16 && kn.bnk_tw != 16 && !o4 && !asym16x;
     const int TW = wide ? 32 : 16;
     a.tiles_y = (Hp + a.TH - 1) / a.TH;
     a.tiles_x = (Wp + TW - 1) / TW;
@@ -1398,11 +1474,13 @@ hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W,
     const double f = Cin / 4.0;
     const double taps = asym ? 10.0 : 9.0;
     // one profile row per kernel symbol, as rocprofv3 lists them
-    ProfScope prof(asym ? (wide ? "k_bottleneck_mfma_asym<32>" : "k_bottleneck_mfma_asym<16>")
+    ProfScope prof(asym16x ? "k_bottleneck_mfma_asym16x" : asym ? (wide ? "k_bottleneck_mfma_asym<32>" : "k_bottleneck_mfma_asym<16>")
                         : o4 ? "k_bottleneck_o4" : (wide ? "k_bottleneck_mfma<32>" : "k_bottleneck_mfma<16>"),
                    2.0 * pix * (Cin * f + taps * f * f + f * Cin),
                    4.0 * (2.0 * pix * Cin + Cin * f * 2.0 + taps * f * f), s);
-    if (asym) {
+    if (asym16x) {
+        hipLaunchKernelGGL(k_bottleneck_mfma_asym16x, dim3((unsigned)launch_grid), dim3(256), 0, s, a);
+    } else if (asym) {
         if (wide)
             hipLaunchKernelGGL(k_bottleneck_mfma_asym<32>, dim3((unsigned)launch_grid), dim3(256), 0, s, a);
         else

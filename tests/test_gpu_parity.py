@@ -291,10 +291,17 @@ def test_bottleneck_tile_shapes_bit_identical(enet_c3k19, name):
             _lib.set_knob("bnk_o4", o4)
             got = layer(xd, training=False)
             assert torch.equal(got, ref), "bnk_o4=%d (k_bottleneck_o4: 8x16 tiles, four workgroups per CU) differs" % o4
+        # asymmetric block: the default k_bottleneck_mfma_asym16x (8x16 tiles, the (5,1) result written over the projected
+        # rows, three workgroups per CU) against the 8x32 / two-halves kernel of rounds 1-4
+        assert _lib.get_knobs()["asym_tw16"] == 1
+        _lib.set_knob("asym_tw16", 0)
+        got = layer(xd, training=False)
+        assert torch.equal(got, ref), "asym_tw16=0 (k_bottleneck_mfma_asym<32>) differs from the default kernel"
     finally:
         _lib.set_knob("bnk_tw", 0)
         _lib.set_knob("bnk_xcd", 1)
         _lib.set_knob("bnk_o4", 2)
+        _lib.set_knob("asym_tw16", 1)
     want = orc.bottleneck(P, name, x[1:2], dil=layer.dilation_rate[0], asym=layer.asymmetric)
     report_diff(name + " [128,256] vs oracle (bit-exact)", ref[1:2].cpu().numpy(), want)
 

@@ -345,10 +345,12 @@ def test_bench_scaling_default_and_common_step_count():
 
 def test_bench_kernel_roofline_rows_and_committed_pmc():
     """bench.kernel_roofline: bound from the arithmetic intensity against the fp32 ridge, achieved / frac per launch, PMC
-    traffic per launch from the newest committed pass (profiles/r04_pmc); packed-vector kernels are labelled as such"""
+    traffic per launch from the newest committed pass (profiles/r05_pmc, with the opt-in kernels' own pass merged in); packed-vector
+    kernels are labelled as such"""
     import bench
     rnd, pmc = bench.load_pmc("enet")
-    assert rnd == "r04" and "k_bottleneck_mfma<32>" in pmc and "k_final_score<fused 5_1>" in pmc and "k_initial_down16" in pmc
+    assert rnd == "r05" and "k_bottleneck_mfma<32>" in pmc and "k_final_score<fused 5_1>" in pmc and "k_initial_down16" in pmc
+    assert "k_bottleneck_bf16x3" in pmc and "k_bottleneck_asym_bf16x3" in pmc
     d = {"launches": 30, "ms": 30 * 0.114, "flops": 30 * 9.127e9, "bytes": 30 * 268.5e6}
     r = bench.kernel_roofline("k_bottleneck_mfma<32>", d, 3, pmc["k_bottleneck_mfma<32>"])
     assert r["bound"] == "mfma" and r["pipe"] == "mfma" and r["launches_per_batch"] == 10 and abs(r["avg_us"] - 114.0) < 1e-6
@@ -441,3 +443,27 @@ def test_last_call_state_is_per_thread_and_never_another_devices_handle():
     d._handles = {3: ["h3", None]}
     d._note_call(FakeWs(5), (1, 8, 8), "forward")
     assert d._handle is None  # device 5 has no handle: None, not device 3's
+
+
+def test_bench_bf16x3_rows_and_compact_leg():
+    """the opt-in leg is priced on the bf16 pipe (six products per fp32 product against the dense bf16 peak) and stays a
+    SECONDARY leg of the line: its own dtype string, its score check within 1e-6 instead of the bit digest, its own roofline row"""
+    import bench
+    row = bench.kernel_roofline("k_bottleneck_bf16x3", {"launches": 12, "ms": 12 * 0.088, "flops": 12 * 9.127e9, "bytes": 12 * 268.5e6}, 1,
+                                {"hbm_bytes_per_launch": 416.6e6})
+    assert row["bound"] == "hbm" and row["pipe"].startswith("mfma bf16") and abs(row["flops"] - 6 * 9.127e9) < 1e6
+    assert abs(row["frac"] - 268.5e6 / 88e-6 / 8e12) < 1e-3 and abs(row["traffic_over_algorithmic"] - 416.6 / 268.5) < 1e-3
+    exact = bench.kernel_roofline("k_bottleneck_mfma<32>", {"launches": 10, "ms": 1.10, "flops": 10 * 9.127e9, "bytes": 10 * 268.5e6}, 1, None)
+    assert exact["bound"] == "mfma" and exact["peak"] == bench.FP32_PEAK_TFLOPS
+    full = json.load(open(os.path.join(os.path.dirname(bench.__file__), "profiles", "r05_bench_enet_full_pool_detail.json")))
+    leg = full["secondary"]["c2_bf16x3"]
+    assert leg["arithmetic"] == "bf16x3" and "bf16x3" in leg["dtype"] and full["dtype"] == "f32"
+    assert leg["score_digest"]["within_tolerance"] and not leg["score_digest"]["bit_identical_to_table"]
+    assert leg["score_digest"]["max_abs_diff"] <= 1e-6 and full["score_digest"]["match"] is True
+    line = json.loads(bench.compact_line(full, os.path.join(bench.ROOT, "gpurun_out", "bench_detail.json")))
+    assert len(json.dumps(line)) <= bench.LINE_LIMIT
+    c = line["secondary"]["c2_bf16x3"]
+    assert c["dtype"].startswith("f32 via bf16x3") and "opt-in" in c["parity"] and c["roofline_bf16x3"]["bound"] == "hbm"
+    assert set(line["secondary"]) == {"c4", "c5", "c2_bf16x3"}
+    for k in ("pass_no_overlap_bound", "pass_overlap_bound"):
+        assert line["roofline"][k]["images_per_s"] > line["value"]

@@ -106,6 +106,7 @@ struct DevLayer {
     const float *exp_w = nullptr, *exp_scale = nullptr, *exp_shift = nullptr;
     const float *res_w = nullptr, *res_alpha = nullptr;
     const float *convT_stacked = nullptr;  // Upsample: [6][f][2*cf] parity-stacked transposed-conv kernel
+    const float *wq = nullptr;   // regular 128-channel blocks: wp | wc | we in quad layout (bnk_quad_layout)
     const float *bf3 = nullptr;  // SSAL_ARITH_BF16X3: the block's kernels pre-split into bf16 triples (ssal_bf16x3.h); NULL where the mode has no kernel
 };
 
@@ -389,6 +390,12 @@ SSAL_API int ssal_enet_commit(ssal_enet *net, void *stream)
             o.v[12] = sp.kind == K_UP ? ab.push(T(net, n + "res_kernel")) : 0;
             o.v[13] = ab.push(T(net, n + "residual_alpha"));
             o.v[14] = sp.kind == K_UP ? ab.push(stack_convT(T(net, n + "conv_kernel"), cf, f)) : 0;
+            o.v[17] = 0;
+            if (sp.kind == K_REGULAR && c == 128 && f == 32)
+                o.v[17] = ab.push(bnk_quad_layout(T(net, n + "proj_kernel").data(),
+                                                  T(net, n + (sp.asym ? "conv_kernel.0" : "conv_kernel")).data(),
+                                                  sp.asym ? T(net, n + "conv_kernel.1").data() : nullptr, sp.asym ? 10 : 9,
+                                                  T(net, n + "exp_kernel").data()));
             o.v[15] = 0;
             if (sp.kind == K_REGULAR && bottleneck_bf16x3_supported(c, f))  // the opt-in arithmetic mode: 104 / 112 KB per layer
                 o.v[15] = ab.push(bf16x3::pack_layer(T(net, n + "proj_kernel").data(),
@@ -442,6 +449,7 @@ SSAL_API int ssal_enet_commit(ssal_enet *net, void *stream)
             L.res_alpha = A + o.v[13];
             L.convT_stacked = L.kind == K_UP ? A + o.v[14] : nullptr;
             L.bf3 = o.v[15] ? A + o.v[15] : nullptr;
+            L.wq = o.v[17] ? A + o.v[17] : nullptr;
             break;
         }
     }
@@ -543,7 +551,7 @@ hipError_t run_regular(const DevLayer &L, const float *x, int n, int h, int w, f
         return launch_bottleneck_mfma(x, y, n, h, w, C, L.dil, L.proj_w, L.proj_scale, L.proj_shift,
                                       L.proj_alpha, L.conv_w, L.asym ? L.conv_w1 : nullptr,
                                       L.conv_scale, L.conv_shift, L.conv_alpha, L.exp_w, L.exp_scale,
-                                      L.exp_shift, L.res_alpha, s);
+                                      L.exp_shift, L.res_alpha, s, L.wq);
     ConvArgs p = conv_args(x, n, h, w, C, L.proj_w, 1, 1, f, 1, 1, T.t0);
     p.scale = L.proj_scale; p.shift = L.proj_shift; p.alpha = L.proj_alpha;
     HIP_RET(launch_conv(p, s));

@@ -14,6 +14,13 @@
 
 namespace ssal {
 
+// float offsets of the three kernels inside BnkArgs::wq (each [chunk][q][lane 64][4]: element i = the fragment of MFMA step 4 q + i)
+namespace quad {
+constexpr int WP = 0, WC = 128 * 32;                                              // wp: 16 quads; wc: taps x 4 quads
+constexpr __host__ __device__ int we(int taps) { return WC + taps * 32 * 32; }     // we: 4 N-tiles x 4 quads
+constexpr __host__ __device__ int total(int taps) { return we(taps) + 32 * 128; }
+}
+
 // regular / dilated / asymmetric bottleneck (enet_modules.py:526-599)
 struct BnkArgs {
     const float *x;
@@ -22,6 +29,7 @@ struct BnkArgs {
     const float *wc, *cs, *ct, *ca;  // conv kernel [3][3][32][32] (HWIO; [5][1][32][32] if asym), folded BN, alpha
     const float *wc2;                // asymmetric only: second kernel [1][5][32][32]
     const float *we, *es, *et, *ra;  // exp kernel [32][128], folded BN, residual alpha
+    const float *wq;                 // regular 128-channel block: wp | wc (asymmetric: the (5,1) kernel then the (1,5) kernel) | we in QUAD layout (quad::, ssal_host.h: bnk_quad_layout)
     int N, H, W, dil;
     int TH;                // tile rows (phase space)
     int tiles_y, tiles_x;  // tiles per phase sub-image (sized for the largest phase)

@@ -47,7 +47,10 @@ constexpr int PMAX = 352;     // >= (TH+2)*(TW+2) rounded up to a multiple of 32
 // ---- phase A (shared by the regular and the asymmetric kernel): 1x1 projection + BN + PReLU of the
 // halo'd tile into LDS; pixels outside the image are written as exact zeros (SAME padding of the
 // following conv applies to the PROJECTED tensor).  HALO = 1 (3x3) or 2 (5x1 / 1x5).
-template <int TW, int HALO, typename Args>
+// WQ: the kernel fragments come from the QUAD layout a.wq (ssal_host.h: bnk_quad_layout; round 5): element i of float4
+// (q, lane) = the fragment of MFMA step 4 q + i -- one buffer_load_b128 per four steps instead of four buffer_load_b32
+// (the round-5 counters show the vector-memory address unit 56 % busy in this kernel, 750 load instructions per wave)
+template <int TW, int HALO, typename Args, bool WQ = false>
 __device__ __forceinline__ void proj_to_lds(const Args &a, const float *ximg, float *P, int TH,
                                             int ty0, int tx0, int py, int px, int Hp, int Wp,
                                             int wave, int j, int h, int prows = PMAX)
@@ -60,12 +63,23 @@ __device__ __forceinline__ void proj_to_lds(const Args &a, const float *ximg, fl
     // The first KEEP k-pair steps stay in registers; the tail is re-fetched (L1) per M-tile into the
     // registers the first activation fragments have just vacated -- this keeps the kernel at 168 VGPRs
     // = 3 workgroups per CU.
-    constexpr int KEEP = 36, UK = KEEP / 4;  // UK = float4 fragments covered by the resident part (24 .. 48 swept in round 4: profiles/r04_ab_keep_sweep.txt)
+#ifndef SSAL_KEEP
+#define SSAL_KEEP 36
+#endif
+    constexpr int KEEP = SSAL_KEEP, UK = KEEP / 4;  // UK = float4 fragments covered by the resident part (24 .. 48 swept in round 4: profiles/r04_ab_keep_sweep.txt)
     float wpr[KEEP];
-    const rsrc_t wrs = make_rsrc(a.wp, C * F * 4);
-    const unsigned wlo = (unsigned)(h * 32 + j) * 4u;
+    const rsrc_t wrs = make_rsrc(WQ ? a.wq + quad::WP : a.wp, C * F * 4);
+    const unsigned wlo = WQ ? (unsigned)(h * 32 + j) * 16u : (unsigned)(h * 32 + j) * 4u;
+    if (WQ) {
 #pragma unroll
-    for (int s = 0; s < KEEP; ++s) wpr[s] = bload(wrs, wlo, s * 256);
+        for (int q = 0; q < KEEP / 4; ++q) {
+            const float4 w4 = bload4(wrs, wlo, q * 1024);
+            wpr[4 * q] = w4.x; wpr[4 * q + 1] = w4.y; wpr[4 * q + 2] = w4.z; wpr[4 * q + 3] = w4.w;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < KEEP; ++s) wpr[s] = bload(wrs, wlo, s * 256);
+    }
     const float bs = a.ps[j], bt = a.pt[j], ba = a.pa[j];
 
     const int nmt = (npix_halo + 31) / 32;
@@ -108,8 +122,16 @@ __device__ __forceinline__ void proj_to_lds(const Args &a, const float *ximg, fl
             step(u, wpr[4 * u], wpr[4 * u + 1], wpr[4 * u + 2], wpr[4 * u + 3]);
         __builtin_amdgcn_sched_barrier(0);
         float wt[64 - KEEP];
+        if (WQ) {
 #pragma unroll
-        for (int s = KEEP; s < 64; ++s) wt[s - KEEP] = bload(wrs, wlo, s * 256);
+            for (int q = KEEP / 4; q < 16; ++q) {
+                const float4 w4 = bload4(wrs, wlo, q * 1024);
+                wt[4 * q - KEEP] = w4.x; wt[4 * q + 1 - KEEP] = w4.y; wt[4 * q + 2 - KEEP] = w4.z; wt[4 * q + 3 - KEEP] = w4.w;
+            }
+        } else {
+#pragma unroll
+            for (int s = KEEP; s < 64; ++s) wt[s - KEEP] = bload(wrs, wlo, s * 256);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = U1; u < UK; ++u)
@@ -185,17 +207,20 @@ __device__ __forceinline__ void conv5x1_to_lds(const BnkArgs &a, const float *P,
 // pixels (registers), cols = co (lanes); taps one ahead as in conv5x1_to_lds
 template <int TW>
 __device__ __forceinline__ f32x16 conv5x1_tile(const BnkArgs &a, const float *P, int u0, int j, int h)
-{
+{   // kernel fragments from the quad layout (taps 0..4 of a.wq's convolution part)
     constexpr int HWP = TW + 4;
-    const rsrc_t wrs = make_rsrc(a.wc, 5 * F * F * 4);
-    const unsigned lo = (unsigned)(h * 32 + j) * 4u;
+    const rsrc_t wrs = make_rsrc(a.wq + quad::WC, 5 * F * F * 4);
+    const unsigned lo = (unsigned)(h * 32 + j) * 16u;
     const int u = u0 + j;
     f32x16 acc = {0};
     float wA[16], wB[16];
     float2 pA[8], pB[8];
     auto load_tap = [&](int kh, float (&w)[16], float2 (&pv)[8]) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) w[k] = bload(wrs, lo, kh * (F * F * 4) + k * 256);  // W0[kh][2k + h][j]
+        for (int q = 0; q < 4; ++q) {  // W0[kh][2 (4q + i) + h][j], i = 0..3
+            const float4 w4 = bload4(wrs, lo, kh * (F * F * 4) + q * 1024);
+            w[4 * q] = w4.x; w[4 * q + 1] = w4.y; w[4 * q + 2] = w4.z; w[4 * q + 3] = w4.w;
+        }
         const float *pq = P + (u + kh * HWP) * PSTR;
 #pragma unroll
         for (int sq = 0; sq < 8; ++sq) pv[sq] = *reinterpret_cast<const float2 *>(pq + kperm_rd(sq, h));
@@ -228,10 +253,10 @@ __device__ __forceinline__ f32x16 conv5x1_tile(const BnkArgs &a, const float *P,
 // qv[ord(s)] of lane (pixel j, half h) = Q[pixel][ci = 2s + h].
 // WRAP > 0 (asymmetric block, second half): S is a ring of WRAP pixel slots, the pixel index is shifted by
 // soff (< 0) and indices that become negative wrap to the end of the ring.
-template <int TW, int KH, int KW, int SW, typename Args, int WRAP = 0>
+template <int TW, int KH, int KW, int SW, typename Args, int WRAP = 0, bool WQ = false>
 __device__ __forceinline__ void conv_tile_q(const Args &a, const float *S, const float *wconv, int mt,
                                             int j, int h, float (&qv)[16], int soff = 0)
-{
+{   // WQ: wconv is the QUAD layout [tap][q][lane][4] (see proj_to_lds)
     const int t = mt * 32 + j;  // this lane's output pixel inside the tile (B operand)
     const int r = t / TW, c = t - r * TW;
     f32x16 acc = {0};
@@ -243,12 +268,20 @@ __device__ __forceinline__ void conv_tile_q(const Args &a, const float *S, const
     float wA[16], wB[16];
     float2 pA[8], pB[8];
     const rsrc_t wrs = make_rsrc(wconv, NTAP * F * F * 4);
-    const unsigned lo = (unsigned)(h * 32 + j) * 4u;
+    const unsigned lo = WQ ? (unsigned)(h * 32 + j) * 16u : (unsigned)(h * 32 + j) * 4u;
     auto load_tap = [&](int tap, float (&w)[16], float2 (&p)[8]) {
         const int kh = tap / KW, kw = tap - KW * kh;
+        if (WQ) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k)  // W[tap][ci = 2k + h][co = j]: rows 2k, 2k+1 = 64 consecutive floats
-            w[k] = bload(wrs, lo, tap * (F * F * 4) + k * 256);
+            for (int q = 0; q < 4; ++q) {
+                const float4 w4 = bload4(wrs, lo, tap * (F * F * 4) + q * 1024);
+                w[4 * q] = w4.x; w[4 * q + 1] = w4.y; w[4 * q + 2] = w4.z; w[4 * q + 3] = w4.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k)  // W[tap][ci = 2k + h][co = j]: rows 2k, 2k+1 = 64 consecutive floats
+                w[k] = bload(wrs, lo, tap * (F * F * 4) + k * 256);
+        }
         int slot = (r + kh) * SW + (c + kw);
         if (WRAP > 0) {
             slot += soff;
@@ -298,7 +331,7 @@ __device__ __forceinline__ void conv_tile_q(const Args &a, const float *S, const
 
 // ---- last phase of the regular / asymmetric bottleneck: conv, then 1x1 expansion + BN + identity
 // residual + PReLU straight to HBM.
-template <int TW, int KH, int KW, int SW, int WRAP = 0>
+template <int TW, int KH, int KW, int SW, int WRAP = 0, bool WQ = false>
 __device__ __forceinline__ void conv_exp_store(const BnkArgs &a, const float *ximg, float *yimg,
                                                const float *S, const float *wconv, int TH, int ty0,
                                                int tx0, int py, int px, int Hp, int Wp, int wave,
@@ -317,12 +350,12 @@ __device__ __forceinline__ void conv_exp_store(const BnkArgs &a, const float *xi
     const unsigned ybytes = (SSAL_ABLATE_IS(a, 4) || SSAL_ABLATE_IS(a, 5) || SSAL_ABLATE_IS(a, 7)) ? 0u : img_bytes;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ximg), 0, xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yimg, 0, ybytes, 0x00020000);
-    const rsrc_t wers = make_rsrc(a.we, F * C * 4), esrs = make_rsrc(a.es, C * 4), etrs = make_rsrc(a.et, C * 4),
+    const rsrc_t wers = make_rsrc(WQ ? a.wq + quad::we(KH * KW == 9 ? 9 : 10) : a.we, F * C * 4), esrs = make_rsrc(a.es, C * 4), etrs = make_rsrc(a.et, C * 4),
                  rars = make_rsrc(a.ra, C * 4);
-    const unsigned welo = (unsigned)(h * C + j) * 4u;
+    const unsigned welo = WQ ? (unsigned)(h * 32 + j) * 16u : (unsigned)(h * C + j) * 4u;
     for (int mt = wave; mt < nmt_out; mt += 4) {
         float qv[16];
-        conv_tile_q<TW, KH, KW, SW, BnkArgs, WRAP>(a, S, wconv, mt, j, h, qv, soff);
+        conv_tile_q<TW, KH, KW, SW, BnkArgs, WRAP, WQ>(a, S, wconv, mt, j, h, qv, soff);
         tr.mark(trk++);  // 3, 5: conv of this wave's 1st / 2nd M-tile done
 
         // BYTE offsets (inside image n) of the 16 output rows this lane-half stores, lane channel folded
@@ -346,8 +379,16 @@ __device__ __forceinline__ void conv_exp_store(const BnkArgs &a, const float *xi
         float weA[16], weB[16], rxA[16], rxB[16];
         float sA, tA, aA, sB, tB, aB;
         auto fetch = [&](int nt, float (&we)[16], float (&rx)[16], float &s1, float &t1, float &al) {
+            if (WQ) {  // quad layout [nt][q][lane][4]
 #pragma unroll
-            for (int k = 0; k < 16; ++k) we[k] = bload(wers, welo, k * (2 * C * 4) + nt * 128);  // We[2k + h][nt*32 + j]
+                for (int q = 0; q < 4; ++q) {
+                    const float4 w4 = bload4(wers, welo, nt * 4096 + q * 1024);
+                    we[4 * q] = w4.x; we[4 * q + 1] = w4.y; we[4 * q + 2] = w4.z; we[4 * q + 3] = w4.w;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) we[k] = bload(wers, welo, k * (2 * C * 4) + nt * 128);  // We[2k + h][nt*32 + j]
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) rx[i] = bload(xrs, boff[i], nt * 128);
             s1 = bload(esrs, j * 4, nt * 128); t1 = bload(etrs, j * 4, nt * 128); al = bload(rars, j * 4, nt * 128);
@@ -435,13 +476,13 @@ __global__ __launch_bounds__(256, 3) void k_bottleneck_mfma(BnkArgs a)
     const float *ximg = a.x + (long)t.n * a.H * a.W * C;
     float *yimg = a.y + (long)t.n * a.H * a.W * C;
     if (!SSAL_ABLATE_IS(a, 2))
-        proj_to_lds<TW, 1>(a, ximg, P, t.TH, t.ty0, t.tx0, t.py, t.px, t.Hp, t.Wp, wave, j, h);
+        proj_to_lds<TW, 1, BnkArgs, true>(a, ximg, P, t.TH, t.ty0, t.tx0, t.py, t.px, t.Hp, t.Wp, wave, j, h);
     tr.mark(1);
     __syncthreads();
     tr.mark(2);
     if (SSAL_ABLATE_IS(a, 1)) return;
-    conv_exp_store<TW, 3, 3, TW + 2>(a, ximg, yimg, P, a.wc, t.TH, t.ty0, t.tx0, t.py, t.px, t.Hp,
-                                     t.Wp, wave, j, h, tr);
+    conv_exp_store<TW, 3, 3, TW + 2, 0, true>(a, ximg, yimg, P, a.wq + quad::WC, t.TH, t.ty0, t.tx0, t.py, t.px, t.Hp,
+                                              t.Wp, wave, j, h, tr);
 #ifdef SSAL_PHASE_TRACE
     __builtin_amdgcn_s_waitcnt(0);  // mark 7 = all stores acknowledged
 #endif
@@ -583,7 +624,7 @@ __global__ __launch_bounds__(256, 4) void k_bottleneck_o4(BnkArgs a)
     };
     fetch_rx(0, rxA);  // the first residual rows travel while the convolution runs
     float qv[16];
-    conv_tile_q<TW, 3, 3, HWP>(a, P, a.wc, mt, j, h, qv);
+    conv_tile_q<TW, 3, 3, HWP, BnkArgs, 0, true>(a, P, a.wq + quad::WC, mt, j, h, qv);
     tr.mark(3);
     fetch_rx(1, rxB);
     __syncthreads();  // the expansion kernel is in WL (written by every thread before its convolution)
@@ -715,7 +756,7 @@ __global__ __launch_bounds__(256, 3) void k_bottleneck_mfma_asym16x(BnkArgs a)
     const float *ximg = a.x + (long)t.n * a.H * a.W * C;
     float *yimg = a.y + (long)t.n * a.H * a.W * C;
     PhaseTrace tr;
-    proj_to_lds<TW, 2>(a, ximg, P, t.TH, t.ty0, t.tx0, t.py, t.px, t.Hp, t.Wp, wave, j, h, PROWS_ASYM16);
+    proj_to_lds<TW, 2, BnkArgs, true>(a, ximg, P, t.TH, t.ty0, t.tx0, t.py, t.px, t.Hp, t.Wp, wave, j, h, PROWS_ASYM16);
     __syncthreads();  // P complete
     const f32x16 r0 = conv5x1_tile<TW>(a, P, wave * 32, j, h);
     f32x16 r1 = {0};
@@ -728,7 +769,8 @@ __global__ __launch_bounds__(256, 3) void k_bottleneck_mfma_asym16x(BnkArgs a)
         if (wave == 0) P[(128 + ri) * PSTR + kperm(j)] = r1[i];
     }
     __syncthreads();  // R complete: result pixel (r, c') in row r * HWP + c'
-    conv_exp_store<TW, 1, 5, HWP>(a, ximg, yimg, P, a.wc2, 8, t.ty0, t.tx0, t.py, t.px, t.Hp, t.Wp, wave, j, h, tr);
+    conv_exp_store<TW, 1, 5, HWP, 0, true>(a, ximg, yimg, P, a.wq + quad::WC + 5 * F * F, 8, t.ty0, t.tx0, t.py, t.px, t.Hp, t.Wp, wave, j,
+                                           h, tr);
 }
 
 // =================================================================================================
@@ -1434,16 +1476,18 @@ hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W,
                                   const float *wp, const float *ps, const float *pt, const float *pa,
                                   const float *wc, const float *wc2, const float *cs, const float *ct,
                                   const float *ca, const float *we, const float *es, const float *et,
-                                  const float *ra, hipStream_t s)
+                                  const float *ra, hipStream_t s, const float *wq)
 {
     if (dil < 1 || dil > 64) return hipErrorInvalidValue;
     const bool asym = wc2 != nullptr;
+    if (Cin == C && !wq && (!asym || knobs().asym_tw16)) return hipErrorInvalidValue;  // these kernels read the quad layout
     if (asym && (dil != 1 || Cin != C)) return hipErrorInvalidValue;
     BnkArgs a;
     a.x = x; a.y = y;
     a.wp = wp; a.ps = ps; a.pt = pt; a.pa = pa;
     a.wc = wc; a.wc2 = wc2; a.cs = cs; a.ct = ct; a.ca = ca;
     a.we = we; a.es = es; a.et = et; a.ra = ra;
+    a.wq = wq;
     a.N = N; a.H = H; a.W = W; a.dil = dil;
     const Knobs &kn = knobs();
 #ifdef SSAL_MEASURE

@@ -49,6 +49,29 @@ struct ArenaBuilder {
     size_t push(const std::vector<float> &v) { return push(v.data(), v.size()); }
 };
 
+// QUAD layout of the regular 128-channel bottleneck's kernels (csrc/ssal_bottleneck_args.h: quad::): for every group of four MFMA
+// steps the four fragments of a lane sit in one float4 -- wp [128][32]: (q, lane (j, h), i) = wp[2 (4q + i) + h][j], q < 16;
+// wc [taps][32][32]: (tap, q, lane, i) = wc[tap][2 (4q + i) + h][j], q < 4; we [32][128]: (nt, q, lane, i) = we[2 (4q + i) + h][32 nt + j]
+inline std::vector<float> bnk_quad_layout(const float *wp, const float *wc, const float *wc2, int taps, const float *we)
+{   // wc2 != NULL (asymmetric block, taps = 10): taps 0..4 = wc (the (5,1) kernel), 5..9 = wc2 (the (1,5) kernel)
+    std::vector<float> out((size_t)128 * 32 + (size_t)taps * 32 * 32 + 32 * 128);
+    size_t o = 0;
+    for (int q = 0; q < 16; ++q)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int i = 0; i < 4; ++i) out[o++] = wp[(2 * (4 * q + i) + (lane >> 5)) * 32 + (lane & 31)];
+    for (int tap = 0; tap < taps; ++tap) {
+        const float *w = (wc2 && tap >= 5) ? wc2 + (size_t)(tap - 5) * 32 * 32 : wc + (size_t)tap * 32 * 32;
+        for (int q = 0; q < 4; ++q)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 4; ++i) out[o++] = w[(2 * (4 * q + i) + (lane >> 5)) * 32 + (lane & 31)];
+    }
+    for (int nt = 0; nt < 4; ++nt)
+        for (int q = 0; q < 4; ++q)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 4; ++i) out[o++] = we[(2 * (4 * q + i) + (lane >> 5)) * 128 + 32 * nt + (lane & 31)];
+    return out;
+}
+
 // bump allocator over a caller-owned workspace (base == NULL: size query)
 struct Bump {
     char *base;

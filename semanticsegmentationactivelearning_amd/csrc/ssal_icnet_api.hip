@@ -79,6 +79,7 @@ struct ConvDev {
     const float *scale = nullptr;  // [CoutP]
     const float *shift = nullptr;  // [CoutP]
     const float *w_hwio = nullptr; // plain HWIO copy: only the layers of the blocks in fused_bneck() (else NULL)
+    const float *wq = nullptr;     // on the *_1x1_reduce layer of a fused_bneck() block: its three kernels in quad layout (bnk_quad_layout)
 };
 
 // identity-shortcut bottlenecks with ENet's stage-2 shape (128 -> 32 -> 3x3 -> 128 on the 1/8-resolution map): the score
@@ -294,7 +295,7 @@ hipError_t run_trunk(const ssal_icnet *net, std::vector<Grp> &grp, bool x_is_u8,
             OUT(nm);
             EACH(launch_bottleneck_mfma(q.A(cur), q.A(nm), q.n, ch, cw, b.cin, b.dil, r.w_hwio, r.scale, r.shift,
                                         net->zeros128, c3.w_hwio, nullptr, c3.scale, c3.shift, net->zeros128, inc.w_hwio,
-                                        inc.scale, inc.shift, net->zeros128, q.s));
+                                        inc.scale, inc.shift, net->zeros128, q.s, r.wq));
             cur = nm;
             continue;
         }
@@ -503,7 +504,7 @@ SSAL_API int ssal_icnet_commit(ssal_icnet *net, void *stream)
     for (const auto &t : net->tensors)
         if (!t.set) return fail(SSAL_ESTATE, "tensor '%s' has not been set", t.name.c_str());
     ArenaBuilder ab;
-    struct Off { size_t w, s, t, hwio; };
+    struct Off { size_t w, s, t, hwio, wq; };
     std::map<std::string, Off> offs;
     std::vector<float> s, t, wt;
     std::map<std::string, bool> wants_hwio;
@@ -514,6 +515,13 @@ SSAL_API int ssal_icnet_commit(ssal_icnet *net, void *stream)
     for (const ConvSpec &sp : net->specs) {
         Off o;
         o.hwio = (size_t)-1;
+        o.wq = (size_t)-1;
+        for (int i = 0; i < kNumBnecks; ++i)
+            if (fused_bneck(kBnecks[i]) && sp.name == std::string(kBnecks[i].name) + "_1x1_reduce") {
+                const std::string b = kBnecks[i].name;
+                o.wq = ab.push(bnk_quad_layout(T(net, b + "_1x1_reduce.kernel").data(), T(net, b + "_3x3.kernel").data(), nullptr, 9,
+                                               T(net, b + "_1x1_increase.kernel").data()));
+            }
         if (wants_hwio.count(sp.name)) o.hwio = ab.push(T(net, sp.name + ".kernel"));
         const std::vector<float> &k = T(net, sp.name + ".kernel");
         if (sp.cin % 32 == 0) {
@@ -555,6 +563,7 @@ SSAL_API int ssal_icnet_commit(ssal_icnet *net, void *stream)
         d.scale = net->arena + o.s;
         d.shift = net->arena + o.t;
         d.w_hwio = o.hwio == (size_t)-1 ? nullptr : net->arena + o.hwio;
+        d.wq = o.wq == (size_t)-1 ? nullptr : net->arena + o.wq;
         net->convs[sp.name] = d;
     }
     net->zeros128 = net->arena + zeros_off;

@@ -89,7 +89,8 @@ hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W,
                                   const float *wp, const float *ps, const float *pt, const float *pa,
                                   const float *wc, const float *wc2 /* asym: (1,5) kernel, else NULL */,
                                   const float *cs, const float *ct, const float *ca, const float *we,
-                                  const float *es, const float *et, const float *ra, hipStream_t s);
+                                  const float *es, const float *et, const float *ra, hipStream_t s,
+                                  const float *wq = nullptr /* 128-channel non-asymmetric blocks: wp | wc | we in quad layout (ssal_host.h) */);
 // opt-in SSAL_ARITH_BF16X3 form of the 128-channel regular / dilated / asymmetric block (ssal_bottleneck_bf16x3.hip);
 // packed = the layer's kernels in ssal_bf16x3.h layout (a.wc2 != NULL selects the asymmetric kernel)
 struct BnkArgs;

@@ -701,8 +701,10 @@ hipError_t run_layer_idx(const ssal_enet *net, int li, const void *x, bool x_is_
 {
     const DevLayer &L = net->layers[li];
     // Initial + Bottleneck1_0 in one launch: Initial's output (a0; no endpoint) is never written
+    // (the image window is read in quads of four elements there: a frame pointer that is not aligned to a quad -- 16 bytes for
+    // float32 frames, 4 for uint8 frames -- takes the two-launch form)
     const bool fuse01 = (ssal::knobs().fuse_ends & 1) && g_use_mfma && initial_down16_supported(net->c_in) &&
-                        (long)h * w * 16 < (1L << 31);
+                        (long)h * w * 16 < (1L << 31) && ((uintptr_t)x & (x_is_u8 ? 3 : 15)) == 0;
     if (li == 0) return fuse01 ? hipSuccess : launch_initial(x, x_is_u8, n, h, w, net->c_in, L.w, L.scale, L.shift, L.alpha, V.a0, s);
     if (li == 1 && fuse01) {
         const DevLayer &I = net->layers[0];

@@ -1359,6 +1359,7 @@ Knobs &knobs()
         q.ig_div = 0;
         q.ic_front = IC_FRONT_DEFAULT;
         q.ic_dual = IC_DUAL_DEFAULT;
+        q.ig_sb = IG_SB_DEFAULT;
 #ifdef SSAL_MEASURE  // measurement builds only: the product library reads no environment
         auto env = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
         q.bnk_tw = env("SSAL_BNK_TW", 0);

@@ -55,8 +55,13 @@ constexpr unsigned IG_OOB = 0xFFFFFFFFu;  // a byte offset no tensor reaches: ra
 // runs the SECOND source (a0.x2: 1x1, stride a0.stride2, its own folded batch-norm) through the same K loop and parks
 // y_p = fmaf(acc, scale2, shift2) in registers, pass 1 runs the main convolution and adds y_p where the separate launches
 // add the shortcut tensor they read back -- the same arithmetic, without the shortcut's write + read.
-template <int NT, int UP2, bool DUAL = false>
-__global__ __launch_bounds__(256) void k_igemm(IgemmArgs a0)
+// SB: ONE LDS buffer instead of two (two barriers per chunk: after the last fragment read, after the write of the next
+// chunk): 36.9 KB at NT = 4 and <= 168 VGPRs -- three workgroups per CU instead of two.  Measured (profiles/
+// r05_ab_igemm_single_lds_buffer.txt): the up-sampling form, whose load + interpolation phases are the longest, gains 3 %
+// (conv_sub2 / conv_sub4); the plain form loses 7 % at NT = 4 and gains 1 % at NT = 2; four workgroups per CU (128 VGPRs:
+// 20-37 spilled) lose 4 %.  Used for UP2 = 2 only.
+template <int NT, int UP2, bool DUAL = false, bool SB = false>
+__global__ __launch_bounds__(256, SB ? 3 : 1) void k_igemm(IgemmArgs a0)
 {
     IgemmArgs a = a0;
     constexpr int BM = IG_BM, BN = 32 * NT, LDK = IG_LDK;
@@ -67,10 +72,11 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a0)
 #ifdef SSAL_MEASURE
     constexpr bool MIDWRITE = false;  // the phase trace / phase ablation times the write phase on its own
 #else
-    constexpr bool MIDWRITE = NT >= 2;  // NT = 1: 16 MFMAs per chunk are over before the loads are back
+    constexpr bool MIDWRITE = NT >= 2 && !SB;  // NT = 1: 16 MFMAs per chunk are over before the loads are back
 #endif
     constexpr int WG_A = NT >= 4 ? 1 : 2, WG_B = WG_A + 1;  // 8-k groups after which the A rows / the kernel rows are written
-    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDK];
+    constexpr int NBUF = SB ? 1 : 2;
+    __shared__ __attribute__((aligned(16))) float smem[NBUF * (BM + BN) * LDK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
@@ -266,8 +272,8 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a0)
         const bool more = t + 1 < nchunks;
         // first fragments of this chunk: requested BEFORE the address arithmetic of the next chunk's loads, which hides
         // their LDS latency
-        const float *As = smem + (t & 1) * (BM + BN) * LDK + (32 * wave + r) * LDK + 4 * h;
-        const float *Bs = smem + (t & 1) * (BM + BN) * LDK + BM * LDK + r * LDK + 4 * h;
+        const float *As = smem + (SB ? 0 : t & 1) * (BM + BN) * LDK + (32 * wave + r) * LDK + 4 * h;
+        const float *Bs = smem + (SB ? 0 : t & 1) * (BM + BN) * LDK + BM * LDK + r * LDK + 4 * h;
         // fragments of 8-k group g+1 are requested before the 4*NT MFMAs of group g: the LDS latency hides behind them
         float4 af[2], bf[2][NT];
         af[0] = *reinterpret_cast<const float4 *>(As);
@@ -331,11 +337,12 @@ __global__ __launch_bounds__(256) void k_igemm(IgemmArgs a0)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         TR_MARK(tr_vm);
 #endif
+        if (SB) __syncthreads();  // every wave has read its last fragment of chunk t
         if (!MIDWRITE) {
 #ifdef SSAL_MEASURE
-            if (more && !(a.ablate & 4)) lds_write((t + 1) & 1);
+            if (more && !(a.ablate & 4)) lds_write(SB ? 0 : (t + 1) & 1);
 #else
-            if (more) lds_write((t + 1) & 1);
+            if (more) lds_write(SB ? 0 : (t + 1) & 1);
 #endif
         }
         TR_MARK(tr_wr);
@@ -751,8 +758,10 @@ hipError_t launch_igemm(const float *x, int N, int H, int W, int Cin, const floa
                        : (NT == 4 ? "k_igemm<4>" : NT == 2 ? "k_igemm<2>" : "k_igemm<1>"), flops, bytes, s);
     // the four-adjacent-pixels loader of the up-sampling form (k_igemm<.., 2>): see the kernel's header
     const bool adj = up2 && stride == 1 && a.Wo % 4 == 0 && dil % 2 == 0 && a.pad_l % 2 == 0;
+    const bool sb = adj && NT >= 2 && knobs().ig_sb != 0;  // one LDS buffer, three workgroups per CU (see the kernel's header)
 #define SSAL_IG(N_)                                                                         \
-    if (adj) hipLaunchKernelGGL((k_igemm<N_, 2>), dim3(grid), dim3(256), 0, s, a);         \
+    if (sb) hipLaunchKernelGGL((k_igemm<(N_ < 2 ? 2 : N_), 2, false, true>), dim3(grid), dim3(256), 0, s, a);   \
+    else if (adj) hipLaunchKernelGGL((k_igemm<N_, 2>), dim3(grid), dim3(256), 0, s, a);    \
     else if (up2) hipLaunchKernelGGL((k_igemm<N_, 1>), dim3(grid), dim3(256), 0, s, a);    \
     else hipLaunchKernelGGL((k_igemm<N_, 0>), dim3(grid), dim3(256), 0, s, a)
     if (NT == 4) { SSAL_IG(4); }
@@ -990,25 +999,46 @@ constexpr int PPM_SLOTS = 50;
 __device__ __host__ constexpr int ppm_cbase(int k) { return k == 0 ? 0 : k == 1 ? 1 : k == 2 ? 3 : 6; }
 constexpr int PPM_CSLOTS = 12;
 
-// stage 1: rowsum[n][y][cslot][c] = sum over the slot's columns (ascending) of x[n][y][.][c]
+// stage 1: rowsum[n][y][cslot][c] = sum over the slot's columns (ascending) of x[n][y][.][c].  One thread per (n, y, channel
+// quad) walks the row ONCE and feeds all 12 slots (a column belongs to one slot per pyramid level; neighbouring bins may share
+// a column when W % b != 0): the map is read once instead of once per level, eight 16-byte loads in flight per thread.
 __global__ __launch_bounds__(256) void k_ppm_rowsum(const float4 *__restrict__ x, int N, int H, int W, int C4,
                                                     float4 *__restrict__ rowsum)
 {
-    const long total = (long)N * H * PPM_CSLOTS * C4;
+    const long total = (long)N * H * C4;
     for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
         const int c = (int)(o % C4);
-        const int cs = (int)((o / C4) % PPM_CSLOTS);
-        const long ny = o / ((long)C4 * PPM_CSLOTS);  // n*H + y
-        const int k = cs >= 6 ? 3 : cs >= 3 ? 2 : cs >= 1 ? 1 : 0;
-        const int b = ppm_bins(k), j = cs - ppm_cbase(k);
-        const int x0 = (j * W) / b, x1 = ((j + 1) * W + b - 1) / b;
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 *row = x + ny * W * C4 + c;
-        for (int xx = x0; xx < x1; ++xx) {
-            const float4 v = row[(long)xx * C4];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        const long ny = o / C4;  // n*H + y
+        float4 s[PPM_CSLOTS];
+        int x0[PPM_CSLOTS], x1[PPM_CSLOTS];
+#pragma unroll
+        for (int cs = 0; cs < PPM_CSLOTS; ++cs) {
+            const int k = cs >= 6 ? 3 : cs >= 3 ? 2 : cs >= 1 ? 1 : 0;
+            const int b = ppm_bins(k), j = cs - ppm_cbase(k);
+            x0[cs] = (j * W) / b;
+            x1[cs] = ((j + 1) * W + b - 1) / b;
+            s[cs] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        rowsum[o] = s;
+        const float4 *row = x + ny * W * C4 + c;
+        for (int xb = 0; xb < W; xb += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = row[(long)min(xb + u, W - 1) * C4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int xx = xb + u;
+#pragma unroll
+                for (int cs = 0; cs < PPM_CSLOTS; ++cs) {
+                    const bool in = xx >= x0[cs] && xx < x1[cs];  // xx >= W belongs to no slot
+                    s[cs].x = in ? s[cs].x + v[u].x : s[cs].x;
+                    s[cs].y = in ? s[cs].y + v[u].y : s[cs].y;
+                    s[cs].z = in ? s[cs].z + v[u].z : s[cs].z;
+                    s[cs].w = in ? s[cs].w + v[u].w : s[cs].w;
+                }
+            }
+        }
+#pragma unroll
+        for (int cs = 0; cs < PPM_CSLOTS; ++cs) rowsum[(ny * PPM_CSLOTS + cs) * C4 + c] = s[cs];
     }
 }
 
@@ -1036,39 +1066,83 @@ __global__ __launch_bounds__(256) void k_ppm_pool(const float4 *__restrict__ row
     }
 }
 
+// One thread per (n, column, channel quad) walks the column: the horizontal half of every level's interpolation
+// (top = tl + (tr - tl) * lx per bin row: 1 + 2 + 3 + 6 values) depends on the column only and is formed once -- 24 loads
+// of pooled values per 32 pixels instead of 16 per pixel -- and a pixel selects its two bin rows from registers.  Same
+// formula, same operand order as the per-pixel form (and the oracle): y = ((((x + up1) + up2) + up3) + up6).
+template <int B> struct PpmLevel {  // one pyramid level with B x B bins: its B horizontally interpolated bin rows
+    float4 hor[B];
+    float hs;
+    __device__ __forceinline__ void init(const float4 *__restrict__ pb, int C4, int ox, int H, int W)
+    {
+        const float ws = (float)B / (float)W;
+        const float fx = (float)ox * ws;
+        const int x0 = (int)floorf(fx);
+        const int x1 = min(x0 + 1, B - 1);
+        const float lx = fx - (float)x0;
+        hs = (float)B / (float)H;
+#pragma unroll
+        for (int yb = 0; yb < B; ++yb) {
+            const float4 tl = pb[(yb * B + x0) * C4], tr = pb[(yb * B + x1) * C4];
+            hor[yb] = make_float4(tl.x + (tr.x - tl.x) * lx, tl.y + (tr.y - tl.y) * lx, tl.z + (tr.z - tl.z) * lx,
+                                  tl.w + (tr.w - tl.w) * lx);
+        }
+    }
+    __device__ __forceinline__ void add(float4 &r, int oy) const
+    {
+        const float fy = (float)oy * hs;
+        const int y0 = (int)floorf(fy);
+        const int y1 = min(y0 + 1, B - 1);
+        const float ly = fy - (float)y0;
+        float4 top = hor[0], bot = hor[0];
+#pragma unroll
+        for (int yb = 1; yb < B; ++yb) {
+            const bool st = y0 == yb, sb = y1 == yb;  // component-wise: a ternary over float4 lvalues would select ADDRESSES
+            top.x = st ? hor[yb].x : top.x; top.y = st ? hor[yb].y : top.y; top.z = st ? hor[yb].z : top.z; top.w = st ? hor[yb].w : top.w;
+            bot.x = sb ? hor[yb].x : bot.x; bot.y = sb ? hor[yb].y : bot.y; bot.z = sb ? hor[yb].z : bot.z; bot.w = sb ? hor[yb].w : bot.w;
+        }
+        r.x = r.x + (top.x + (bot.x - top.x) * ly);
+        r.y = r.y + (top.y + (bot.y - top.y) * ly);
+        r.z = r.z + (top.z + (bot.z - top.z) * ly);
+        r.w = r.w + (top.w + (bot.w - top.w) * ly);
+    }
+};
+
 __global__ __launch_bounds__(256) void k_ppm_sum(const float4 *__restrict__ x, const float4 *__restrict__ pooled,
                                                  int N, int H, int W, int C4, float4 *__restrict__ y)
 {
-    const long total = (long)N * H * W * C4;
+    const long total = (long)N * W * C4;
     for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
         const int c = (int)(o % C4);
-        const long pix = o / C4;
-        const int ox = (int)(pix % W);
-        const int oy = (int)((pix / W) % H);
-        const long n = pix / ((long)W * H);
-        float4 v = x[o];
+        const int ox = (int)((o / C4) % W);
+        const long n = o / ((long)C4 * W);
+        const float4 *pn = pooled + n * PPM_SLOTS * C4 + c;
+        PpmLevel<1> l1;
+        PpmLevel<2> l2;
+        PpmLevel<3> l3;
+        PpmLevel<6> l6;
+        l1.init(pn + (long)ppm_base(0) * C4, C4, ox, H, W);
+        l2.init(pn + (long)ppm_base(1) * C4, C4, ox, H, W);
+        l3.init(pn + (long)ppm_base(2) * C4, C4, ox, H, W);
+        l6.init(pn + (long)ppm_base(3) * C4, C4, ox, H, W);
+        const long col = (n * H * W + ox) * C4 + c;
+        for (int yb4 = 0; yb4 < H; yb4 += 4) {
+            float4 v[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int b = ppm_bins(k);
-            const float hs = (float)b / (float)H, ws = (float)b / (float)W;
-            const float fy = (float)oy * hs, fx = (float)ox * ws;
-            const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
-            const int y1 = min(y0 + 1, b - 1), x1 = min(x0 + 1, b - 1);
-            const float ly = fy - (float)y0, lx = fx - (float)x0;
-            const float4 *pb = pooled + (n * PPM_SLOTS + ppm_base(k)) * C4 + c;
-            const float4 tl = pb[(y0 * b + x0) * C4], tr = pb[(y0 * b + x1) * C4];
-            const float4 bl = pb[(y1 * b + x0) * C4], br = pb[(y1 * b + x1) * C4];
-            auto lerp2 = [&](float ctl, float ctr, float cbl, float cbr) {
-                const float top = ctl + (ctr - ctl) * lx;
-                const float bot = cbl + (cbr - cbl) * lx;
-                return top + (bot - top) * ly;
-            };
-            v.x = v.x + lerp2(tl.x, tr.x, bl.x, br.x);
-            v.y = v.y + lerp2(tl.y, tr.y, bl.y, br.y);
-            v.z = v.z + lerp2(tl.z, tr.z, bl.z, br.z);
-            v.w = v.w + lerp2(tl.w, tr.w, bl.w, br.w);
+            for (int u = 0; u < 4; ++u) v[u] = x[col + (long)min(yb4 + u, H - 1) * W * C4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int oy = yb4 + u;
+                if (oy < H) {
+                    float4 r = v[u];
+                    l1.add(r, oy);
+                    l2.add(r, oy);
+                    l3.add(r, oy);
+                    l6.add(r, oy);
+                    y[col + (long)oy * W * C4] = r;
+                }
+            }
         }
-        y[o] = v;
     }
 }
 
@@ -1087,8 +1161,8 @@ hipError_t launch_ppm(const float *x, int N, int H, int W, int C, float *scratch
     float *pooled = scratch;                               // [N][50][C]
     float *rowsum = scratch + (int64_t)N * PPM_SLOTS * C;  // [N][H][12][C]
     {
-        const long total = (long)N * H * PPM_CSLOTS * (C / 4);
-        ProfScope prof("k_ppm_rowsum", 0.0, 4.0 * (4.0 * N * H * W * C + (double)total * 4), s);
+        const long total = (long)N * H * (C / 4);
+        ProfScope prof("k_ppm_rowsum", 0.0, 4.0 * ((double)N * H * W * C + (double)total * PPM_CSLOTS * 4), s);
         hipLaunchKernelGGL(k_ppm_rowsum, dim3(cdiv_i(total, 256)), dim3(256), 0, s, (const float4 *)x, N, H, W, C / 4,
                            (float4 *)rowsum);
     }
@@ -1098,7 +1172,7 @@ hipError_t launch_ppm(const float *x, int N, int H, int W, int C, float *scratch
         hipLaunchKernelGGL(k_ppm_pool, dim3(cdiv_i(total, 256)), dim3(256), 0, s, (const float4 *)rowsum, N, H, W, C / 4,
                            (float4 *)pooled);
     }
-    const long total = (long)N * H * W * (C / 4);
+    const long total = (long)N * W * (C / 4);
     int grid = cdiv_i(total, 256);
     if (grid > 1 << 20) grid = 1 << 20;
     ProfScope prof("k_ppm_sum", 0.0, 8.0 * (double)N * H * W * C, s);

@@ -1200,7 +1200,48 @@ __global__ __launch_bounds__(256) void k_upscore(const float *__restrict__ lq, i
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
     const float inv_logK = 1.0f / logf((float)K);
     double local = 0.0;
-    if (q < (long)H * W) {
+    if (!OUT && q < (long)H * W) {
+        // score only: the interpolation and the softmax front on class pairs (packed fp32: two operations per lane and
+        // issue slot); element for element the operations of the generic body below, in its order
+        constexpr int KP = (K + 1) / 2;
+        typedef score_f32x2 f2;
+        const int qx = (int)(q % W), qy = (int)(q / W);
+        const int qx1 = min(qx + 1, W - 1), qy1 = min(qy + 1, H - 1);
+        const float *img = lq + (long)n * H * W * K;
+        f2 tl2[KP], dt2[KP], bl2[KP], db2[KP];
+        {
+            const float *ptl = img + ((long)qy * W + qx) * K, *ptr_ = img + ((long)qy * W + qx1) * K;
+            const float *pbl = img + ((long)qy1 * W + qx) * K, *pbr = img + ((long)qy1 * W + qx1) * K;
+#pragma unroll
+            for (int p = 0; p < KP; ++p) {
+                const int k0 = 2 * p, k1 = min(2 * p + 1, K - 1);
+                tl2[p] = (f2){ptl[k0], ptl[k1]};
+                bl2[p] = (f2){pbl[k0], pbl[k1]};
+                dt2[p] = (f2){ptr_[k0], ptr_[k1]} - tl2[p];
+                db2[p] = (f2){pbr[k0], pbr[k1]} - bl2[p];
+            }
+        }
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {
+            const float lx = 0.25f * (float)dx;
+            const f2 lx2 = {lx, lx};
+            f2 top2[KP], d2[KP];
+#pragma unroll
+            for (int p = 0; p < KP; ++p) {
+                top2[p] = tl2[p] + dt2[p] * lx2;
+                d2[p] = (bl2[p] + db2[p] * lx2) - top2[p];
+            }
+#pragma unroll
+            for (int dy = 0; dy < 4; ++dy) {
+                const float ly = 0.25f * (float)dy;
+                const f2 ly2 = {ly, ly};
+                f2 l2[KP];
+#pragma unroll
+                for (int p = 0; p < KP; ++p) l2[p] = top2[p] + d2[p] * ly2;
+                local += (double)pixel_score_only_pk<K>(l2, measure, inv_logK);
+            }
+        }
+    } else if (q < (long)H * W) {
         const int qx = (int)(q % W), qy = (int)(q / W);
         const int qx1 = min(qx + 1, W - 1), qy1 = min(qy + 1, H - 1);
         const float *img = lq + (long)n * H * W * K;

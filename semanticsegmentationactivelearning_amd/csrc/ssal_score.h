@@ -90,6 +90,54 @@ __device__ __forceinline__ float pixel_score_only(const float (&l)[K], int measu
     return 1.0f / S;
 }
 
+// The score-only form on class PAIRS (v_pk_add_f32 / v_pk_mul_f32 process two fp32 operations per lane and issue slot): the
+// subtraction of the maximum and the exp2 pre-scale (__expf(d) IS v_exp_f32(d * log2(e)): one multiply, one v_exp) run
+// packed; every operation, and the order of the sums, is pixel_score_only's -- the same bits.  l2[p] = (l[2p], l[2p + 1]);
+// the upper half of the last pair of an odd K is never read.
+typedef float score_f32x2 __attribute__((ext_vector_type(2)));
+template <int K>
+__device__ __forceinline__ float pixel_score_only_pk(const score_f32x2 (&l2)[(K + 1) / 2], int measure, float inv_logK)
+{
+    constexpr int KP = (K + 1) / 2;
+    auto el = [&](int k) { return (k & 1) ? l2[k >> 1].y : l2[k >> 1].x; };
+    const score_f32x2 log2e = {0x1.715476p+0f, 0x1.715476p+0f};
+    float m1 = el(0), m2 = -__builtin_inff();
+    if (measure == 1) {
+#pragma unroll
+        for (int k = 1; k < K; ++k) {
+            m2 = fmaxf(m2, fminf(m1, el(k)));
+            m1 = fmaxf(m1, el(k));
+        }
+    } else {
+#pragma unroll
+        for (int k = 1; k < K; ++k) m1 = fmaxf(m1, el(k));
+    }
+    const score_f32x2 mm = {m1, m1};
+    score_f32x2 d2[KP], p2[KP];
+#pragma unroll
+    for (int p = 0; p < KP; ++p) {
+        d2[p] = l2[p] - mm;
+        p2[p] = d2[p] * log2e;
+    }
+    auto dk = [&](int k) { return (k & 1) ? d2[k >> 1].y : d2[k >> 1].x; };
+    auto ek = [&](int k) { return __builtin_amdgcn_exp2f((k & 1) ? p2[k >> 1].y : p2[k >> 1].x); };
+    float S = 0.0f, T = 0.0f;
+    if (measure == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float e = ek(k);
+            S += e;
+            T = fmaf(e, fmaxf(dk(k), -3.0e38f), T);
+        }
+        const float Hn = __logf(S) - T / S;
+        return 1.0f - Hn * inv_logK;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) S += ek(k);
+    if (measure == 1) return (1.0f - __expf(m2 - m1)) / S;
+    return 1.0f / S;
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll

@@ -1425,6 +1425,7 @@ SSAL_API int ssal_debug_set_knob(const char *name, int value)
     else if (n == "bnk_xcd") k.bnk_xcd = value;
     else if (n == "bnk_o4") k.bnk_o4 = value;
     else if (n == "asym_tw16") k.asym_tw16 = value != 0;
+    else if (n == "bnk_qepi") k.bnk_qepi = value;
     else if (n == "img_groups") k.img_groups = value;
     else if (n == "img_span") k.img_span = value;
     else if (n == "fuse_ends") k.fuse_ends = value;
@@ -1452,11 +1453,11 @@ SSAL_API int ssal_debug_get_knobs(char *json_out, int64_t cap)
     measure = 1;
     ablate = k.ablate + 100 * k.bnk_split;  // any non-zero value makes `defaults` 0: bench.py refuses to time it as a result
 #endif
-    const int dflt = g_use_mfma && k.bnk_tw == 0 && k.bnk_o4 == 2 && k.bnk_xcd == 1 && k.asym_tw16 == ssal::ASYM_TW16_DEFAULT && k.img_groups == 2 && k.img_span == 4 && k.fuse_ends == 3 && k.img_lag == 0 && k.ig_div == 0 && k.ic_front == ssal::IC_FRONT_DEFAULT && k.ic_dual == ssal::IC_DUAL_DEFAULT && k.ig_sb == ssal::IG_SB_DEFAULT && ablate == 0 && !ssal::prof_enabled()
+    const int dflt = g_use_mfma && k.bnk_tw == 0 && k.bnk_o4 == 2 && k.bnk_xcd == 1 && k.asym_tw16 == ssal::ASYM_TW16_DEFAULT && k.bnk_qepi == ssal::BNK_QEPI_DEFAULT && k.img_groups == 2 && k.img_span == 4 && k.fuse_ends == 3 && k.img_lag == 0 && k.ig_div == 0 && k.ic_front == ssal::IC_FRONT_DEFAULT && k.ic_dual == ssal::IC_DUAL_DEFAULT && k.ig_sb == ssal::IG_SB_DEFAULT && ablate == 0 && !ssal::prof_enabled()
                      && ssal::g_trace_buf == nullptr;
-    snprintf(json_out, (size_t)cap, "{\"kernel_family\": %d, \"bnk_tw\": %d, \"bnk_o4\": %d, \"bnk_xcd\": %d, \"asym_tw16\": %d, \"img_groups\": %d, \"img_span\": %d, \"fuse_ends\": %d, "
+    snprintf(json_out, (size_t)cap, "{\"kernel_family\": %d, \"bnk_tw\": %d, \"bnk_o4\": %d, \"bnk_xcd\": %d, \"asym_tw16\": %d, \"bnk_qepi\": %d, \"img_groups\": %d, \"img_span\": %d, \"fuse_ends\": %d, "
              "\"img_lag\": %d, \"ig_div\": %d, \"ic_front\": %d, \"ic_dual\": %d, \"ig_sb\": %d, \"ablate\": %d, \"measure_build\": %d, \"profiling\": %d, \"defaults\": %d}", g_use_mfma ? 1 : 0,
-             k.bnk_tw, k.bnk_o4, k.bnk_xcd, k.asym_tw16, k.img_groups, k.img_span, k.fuse_ends, k.img_lag, k.ig_div, k.ic_front, k.ic_dual, k.ig_sb, ablate, measure, ssal::prof_enabled() ? 1 : 0, dflt);
+             k.bnk_tw, k.bnk_o4, k.bnk_xcd, k.asym_tw16, k.bnk_qepi, k.img_groups, k.img_span, k.fuse_ends, k.img_lag, k.ig_div, k.ic_front, k.ic_dual, k.ig_sb, ablate, measure, ssal::prof_enabled() ? 1 : 0, dflt);
     return SSAL_OK;
 }
 

@@ -331,15 +331,106 @@ __device__ __forceinline__ void conv_tile_q(const Args &a, const float *S, const
 
 // ---- last phase of the regular / asymmetric bottleneck: conv, then 1x1 expansion + BN + identity
 // residual + PReLU straight to HBM.
-template <int TW, int KH, int KW, int SW, int WRAP = 0, bool WQ = false>
+// QEPI = 2 (round 5, needs WQ; k_bottleneck_mfma<32>): the expansion runs as D[co][pixel] (operands swapped: the same products in
+// the same k order, i.e. the same bits; lane = pixel, four consecutive channels per register group), the residual arrives as
+// four 16-byte loads and the output leaves as four 16-byte stores per N-tile -- whole 128-byte rows through quad_transpose4 --
+// instead of 16 + 16 four-byte accesses and three BN loads: 224 -> 116 vector-memory instructions per M-tile for +256 VALU.
+// bnv = es | et | ra staged in LDS by the kernel (the per-channel constants are per REGISTER in this form).  QEPI = 1: the
+// lane's own 16 bytes per store (no transpose; slower).  Measured (profiles/r05_ab_epilogue_co_major_16B.txt): the kernel alone
+// -7 %, the single-chain pass +1 %, the two-chain pass +-0; the asymmetric kernel (one M-tile per wave) loses 7 % with it.
+template <int TW, int KH, int KW, int SW, int WRAP = 0, bool WQ = false, int QEPI = 0>
 __device__ __forceinline__ void conv_exp_store(const BnkArgs &a, const float *ximg, float *yimg,
                                                const float *S, const float *wconv, int TH, int ty0,
                                                int tx0, int py, int px, int Hp, int Wp, int wave,
-                                               int j, int h, PhaseTrace &tr, int soff = 0)
+                                               int j, int h, PhaseTrace &tr, int soff = 0, const float *bnv = nullptr)
 {
     const int d = a.dil;
     const int nmt_out = (TH * TW) / 32;
     int trk = 3;
+    if (QEPI > 0) {
+        const int lane = h * 32 + j;
+        const unsigned img_bytes = (unsigned)(a.H * a.W * C) * 4u;
+        const rsrc_t xrs = make_rsrc(ximg, img_bytes), yrs = make_rsrc(yimg, img_bytes);
+        const rsrc_t wers = make_rsrc(a.wq + quad::we(KH * KW == 9 ? 9 : 10), F * C * 4);
+        const unsigned welo = (unsigned)(h * 32 + j) * 16u;
+        const float *bnl = bnv + 4 * h;  // es | et | ra of channels 32 nt + 8 g + 4 h .. + 3
+        for (int mt = wave; mt < nmt_out; mt += 4) {
+            float qv[16];
+            conv_tile_q<TW, KH, KW, SW, BnkArgs, WRAP, WQ>(a, S, wconv, mt, j, h, qv, soff);
+            if (mt == wave) tr.mark(trk++);
+            // own pixel (residual loads; QEPI = 1 stores) and the four pixels of the lane's quad (QEPI = 2 stores)
+            unsigned xo, yoq[4];
+            {
+                const int ti = mt * 32 + j, rr = ti / TW, cc = ti - rr * TW, pr = ty0 + rr, pc = tx0 + cc;
+                xo = (pr < Hp && pc < Wp) ? (unsigned)(((py + pr * d) * a.W + (px + pc * d)) * (C * 4) + 16 * h) : 0x80000000u;
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int ti = mt * 32 + (j & ~3) + kk, rr = ti / TW, cc = ti - rr * TW, pr = ty0 + rr, pc = tx0 + cc;
+                yoq[kk] = (pr < Hp && pc < Wp) ? (unsigned)(((py + pr * d) * a.W + (px + pc * d)) * (C * 4) + 32 * (j & 3) + 16 * h) : 0x80000000u;
+            }
+            float weA[16], weB[16];
+            float4 rxA[4], rxB[4];
+            auto fetch = [&](int nt, float (&we)[16], float4 (&rx)[4]) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 w4 = bload4(wers, welo, nt * 4096 + q * 1024);
+                    we[4 * q] = w4.x; we[4 * q + 1] = w4.y; we[4 * q + 2] = w4.z; we[4 * q + 3] = w4.w;
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) rx[g] = bload4(xrs, xo, nt * 128 + g * 32);  // channels 32 nt + 8 g + 4 h .. + 3
+            };
+            auto epi = [&](int nt, const f32x16 &e, const float4 (&rx)[4]) {
+                float4 ov[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    asm volatile("" ::: "memory");  // keep the LDS reads here (hoisted they would pin registers)
+                    const float4 s4 = *reinterpret_cast<const float4 *>(bnl + nt * 32 + 8 * g);
+                    const float4 t4 = *reinterpret_cast<const float4 *>(bnl + C + nt * 32 + 8 * g);
+                    const float4 a4 = *reinterpret_cast<const float4 *>(bnl + 2 * C + nt * 32 + 8 * g);
+                    ov[g].x = prelu1(fmaf(e[4 * g + 0], s4.x, t4.x) + rx[g].x, a4.x);
+                    ov[g].y = prelu1(fmaf(e[4 * g + 1], s4.y, t4.y) + rx[g].y, a4.y);
+                    ov[g].z = prelu1(fmaf(e[4 * g + 2], s4.z, t4.z) + rx[g].z, a4.z);
+                    ov[g].w = prelu1(fmaf(e[4 * g + 3], s4.w, t4.w) + rx[g].w, a4.w);
+                }
+                if (QEPI == 2) {
+                    quad_transpose4(ov[0], ov[1], ov[2], ov[3], lane);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov[kk]), yrs, yoq[kk], nt * 128, 0);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov[g]), yrs, xo, nt * 128 + g * 32, 0);
+                }
+            };
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(0, weA, rxA);
+            fetch(1, weB, rxB);
+            f32x16 e0 = {0}, e1 = {0};
+#pragma unroll
+            for (int s = 0; s < 16; ++s) e0 = mfma32(weA[s], qv[ord(s)], e0);  // D[co][pixel]: A = We^T (rows co), B = Q
+#pragma unroll
+            for (int s = 0; s < 16; ++s) e1 = mfma32(weB[s], qv[ord(s)], e1);
+            epi(0, e0, rxA);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(2, weA, rxA);
+            e0 = (f32x16){0};
+#pragma unroll
+            for (int s = 0; s < 16; ++s) e0 = mfma32(weA[s], qv[ord(s)], e0);
+            epi(1, e1, rxB);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(3, weB, rxB);
+            e1 = (f32x16){0};
+#pragma unroll
+            for (int s = 0; s < 16; ++s) e1 = mfma32(weB[s], qv[ord(s)], e1);
+            epi(2, e0, rxA);
+            __builtin_amdgcn_sched_barrier(0);
+            epi(3, e1, rxB);
+            if (mt == wave) tr.mark(trk++);
+        }
+        return;
+    }
     // raw buffer resources over image n of x and y (num_records = image bytes <= 2 GiB); kOOB is an
     // offset the range check always rejects, even after the +384 B N-tile immediates
     constexpr unsigned kOOB = 0x80000000u;
@@ -463,10 +554,16 @@ __device__ __forceinline__ TileId decode_tile(const BnkArgs &a)
 }
 
 // regular / dilated 3x3 bottleneck: 168 VGPRs and 47 KB of LDS = three workgroups per CU
-template <int TW>
+template <int TW, int QEPI = 0>
 __global__ __launch_bounds__(256, 3) void k_bottleneck_mfma(BnkArgs a)
 {
     __shared__ float P[PMAX * PSTR];
+    __shared__ __attribute__((aligned(16))) float BNV[QEPI > 0 ? 3 * C : 4];
+    if (QEPI > 0 && threadIdx.x < 3 * C / 4) {  // es | et | ra: read by every wave only after the barrier below
+        const int arr = threadIdx.x / (C / 4), k4 = threadIdx.x % (C / 4);
+        const float *src = arr == 0 ? a.es : arr == 1 ? a.et : a.ra;
+        reinterpret_cast<float4 *>(BNV)[threadIdx.x] = reinterpret_cast<const float4 *>(src)[k4];
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const TileId t = decode_tile<TW>(a);
@@ -481,8 +578,8 @@ __global__ __launch_bounds__(256, 3) void k_bottleneck_mfma(BnkArgs a)
     __syncthreads();
     tr.mark(2);
     if (SSAL_ABLATE_IS(a, 1)) return;
-    conv_exp_store<TW, 3, 3, TW + 2, 0, true>(a, ximg, yimg, P, a.wq + quad::WC, t.TH, t.ty0, t.tx0, t.py, t.px, t.Hp,
-                                              t.Wp, wave, j, h, tr);
+    conv_exp_store<TW, 3, 3, TW + 2, 0, true, QEPI>(a, ximg, yimg, P, a.wq + quad::WC, t.TH, t.ty0, t.tx0, t.py, t.px, t.Hp,
+                                                    t.Wp, wave, j, h, tr, 0, BNV);
 #ifdef SSAL_PHASE_TRACE
     __builtin_amdgcn_s_waitcnt(0);  // mark 7 = all stores acknowledged
 #endif
@@ -1352,6 +1449,7 @@ Knobs &knobs()
         q.bnk_o4 = 2;
         q.bnk_xcd = 1;
         q.asym_tw16 = ASYM_TW16_DEFAULT;
+        q.bnk_qepi = BNK_QEPI_DEFAULT;
         q.img_groups = 2;
         q.img_span = 4;
         q.fuse_ends = 3;
@@ -1533,7 +1631,11 @@ hipError_t launch_bottleneck_mfma(const float *x, float *y, int N, int H, int W,
     } else if (o4) {
         hipLaunchKernelGGL(k_bottleneck_o4, dim3((unsigned)launch_grid), dim3(256), 0, s, a);
     } else {
-        if (wide)
+        if (wide && kn.bnk_qepi == 1)
+            hipLaunchKernelGGL((k_bottleneck_mfma<32, 1>), dim3((unsigned)launch_grid), dim3(256), 0, s, a);
+        else if (wide && kn.bnk_qepi >= 2)
+            hipLaunchKernelGGL((k_bottleneck_mfma<32, 2>), dim3((unsigned)launch_grid), dim3(256), 0, s, a);
+        else if (wide)
             hipLaunchKernelGGL(k_bottleneck_mfma<32>, dim3((unsigned)launch_grid), dim3(256), 0, s, a);
         else
             hipLaunchKernelGGL(k_bottleneck_mfma<16>, dim3((unsigned)launch_grid), dim3(256), 0, s, a);

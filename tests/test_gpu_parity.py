@@ -297,11 +297,20 @@ def test_bottleneck_tile_shapes_bit_identical(enet_c3k19, name):
         _lib.set_knob("asym_tw16", 0)
         got = layer(xd, training=False)
         assert torch.equal(got, ref), "asym_tw16=0 (k_bottleneck_mfma_asym<32>) differs from the default kernel"
+        _lib.set_knob("asym_tw16", 1)
+        # regular block: the default expansion epilogue of k_bottleneck_mfma<32> (D[co][pixel], 16-byte residual loads, whole-row
+        # stores through quad_transpose4) against the same without the transpose and the D[pixel][co] epilogue of rounds 1-4
+        assert _lib.get_knobs()["bnk_qepi"] == 2
+        for qepi in (1, 0):
+            _lib.set_knob("bnk_qepi", qepi)
+            got = layer(xd, training=False)
+            assert torch.equal(got, ref), "bnk_qepi=%d differs from the default epilogue" % qepi
     finally:
         _lib.set_knob("bnk_tw", 0)
         _lib.set_knob("bnk_xcd", 1)
         _lib.set_knob("bnk_o4", 2)
         _lib.set_knob("asym_tw16", 1)
+        _lib.set_knob("bnk_qepi", 2)
     want = orc.bottleneck(P, name, x[1:2], dil=layer.dilation_rate[0], asym=layer.asymmetric)
     report_diff(name + " [128,256] vs oracle (bit-exact)", ref[1:2].cpu().numpy(), want)
 

@@ -402,6 +402,9 @@ SSAL_API int ssal_enet_commit(ssal_enet *net, void *stream)
                                                      T(net, n + (sp.asym ? "conv_kernel.0" : "conv_kernel")).data(),
                                                      sp.asym ? T(net, n + "conv_kernel.1").data() : nullptr, sp.asym ? 10 : 9,
                                                      T(net, n + "exp_kernel").data()));
+            if (sp.kind == K_DOWN && downsample_bf16x3_supported(c, L.cout))  // Bottleneck2_0 of the opt-in mode (129 KB)
+                o.v[15] = ab.push(bf16x3::pack_down_layer(T(net, n + "proj_kernel").data(), T(net, n + "conv_kernel").data(),
+                                                          T(net, n + "exp_kernel").data()));
             break;
         }
         case K_FINAL:
@@ -577,9 +580,19 @@ hipError_t run_regular(const DevLayer &L, const float *x, int n, int h, int w, f
 
 // BottleneckDownsample.call (enet_modules.py:868-938); code: [n,h/2,w/2,cin] window codes
 hipError_t run_down(const DevLayer &L, const float *x, int n, int h, int w, float *y, uint8_t *code,
-                    const LayerTemps &T, hipStream_t s)
+                    const LayerTemps &T, hipStream_t s, int arith = SSAL_ARITH_F32)
 {
     const int C = L.cin, f = L.f;
+    if (arith == SSAL_ARITH_BF16X3 && L.bf3 && down_fused(L, h, w)) {  // opt-in mode; the pooling residual / codes stay exact
+        DownArgs a;
+        memset(&a, 0, sizeof(a));
+        a.x = x; a.y = y; a.code = code;
+        a.wp = L.proj_w; a.ps = L.proj_scale; a.pt = L.proj_shift; a.pa = L.proj_alpha;
+        a.wc = L.conv_w; a.cs = L.conv_scale; a.ct = L.conv_shift; a.ca = L.conv_alpha;
+        a.we = L.exp_w; a.es = L.exp_scale; a.et = L.exp_shift; a.ra = L.res_alpha;
+        a.N = n; a.H = h; a.W = w;
+        return launch_downsample_bf16x3(a, L.bf3, s);
+    }
     if (down_fused(L, h, w))
         return launch_downsample_mfma(x, y, code, n, h, w, C, L.proj_w, L.proj_scale, L.proj_shift,
                                       L.proj_alpha, L.conv_w, L.conv_scale, L.conv_shift, L.conv_alpha,
@@ -714,7 +727,7 @@ hipError_t run_layer_idx(const ssal_enet *net, int li, const void *x, bool x_is_
     }
     if (li == 1) return run_down(L, V.a0, n, h / 2, w / 2, V.s1a, V.code1, V.T, s);
     if (li <= 5) return run_regular(L, (li - 2) % 2 == 0 ? V.s1a : V.s1b, n, h / 4, w / 4, (li - 2) % 2 == 0 ? V.s1b : V.s1a, V.T, s);
-    if (li == 6) return run_down(L, V.s1a, n, h / 4, w / 4, V.s2a, V.code2, V.T, s);
+    if (li == 6) return run_down(L, V.s1a, n, h / 4, w / 4, V.s2a, V.code2, V.T, s, arith);
     if (li <= 22) return run_regular(L, (li - 7) % 2 == 0 ? V.s2a : V.s2b, n, h / 8, w / 8, (li - 7) % 2 == 0 ? V.s2b : V.s2a, V.T, s, arith);
     if (li == 23) return run_up(L, V.s2a, n, h / 8, w / 8, V.s1a, V.code2, nullptr, V.T, s);
     if (li <= 25) return run_regular(L, li == 24 ? V.s1a : V.s1b, n, h / 4, w / 4, li == 24 ? V.s1b : V.s1a, V.T, s);
@@ -1040,7 +1053,7 @@ static int run_layer_any(ssal_enet *net, const char *layer, const float *x_dev, 
         break;
     case K_DOWN: {
         uint8_t *code = b.take<uint8_t>((int64_t)n * (h / 2) * (w / 2) * L.cin);
-        HIP_TRY(run_down(L, x_dev, n, h, w, y_dev, code, T, s));
+        HIP_TRY(run_down(L, x_dev, n, h, w, y_dev, code, T, s, arith));
         if (argmax_out_dev)
             HIP_TRY(launch_codes_to_argmax(code, n, h / 2, w / 2, L.cin, argmax_out_dev, s));
         break;

@@ -75,5 +75,30 @@ inline std::vector<float> pack_layer(const float *wp, const float *wc, const flo
     return out;
 }
 
+// Downsample bottleneck 64 -> 128 (Bottleneck2_0): wp [2][2][64][32] (K = 4 taps x 64 channels = 16 chunks), wc [9][32][32],
+// we [32][128] (the expansion runs as D[co][pixel] there: the chunk is the A operand, rows = output channels 32 nt + j)
+constexpr int DN_WP_OFF = 0;
+constexpr int DN_WC_OFF = 16 * CHUNK_UNITS;
+constexpr int DN_WE_OFF = DN_WC_OFF + 18 * CHUNK_UNITS;
+constexpr int DN_UNITS = DN_WE_OFF + 8 * CHUNK_UNITS;
+inline std::vector<float> pack_down_layer(const float *wp, const float *wc, const float *we)
+{
+    std::vector<float> out;
+    out.reserve((size_t)DN_UNITS * 4);
+    // chunk s = 4 cc + t: tap t = dy * 2 + dx of channel group cc; k-slot (h, i) = channel 16 cc + 4 h + (i & 3) + 8 (i >> 2) -- a
+    // lane half then holds the channels c with (c >> 2) & 1 == h, the ones a D[co][pixel] accumulator gives it: the pooled
+    // residual of the block meets the expansion's output in the same lane (ssal_bottleneck_bf16x3.hip: project_down)
+    for (int s = 0; s < 16; ++s)
+        pack_chunk(out, [&](int h, int i, int j) {
+            return wp[((s & 3) * 64 + 16 * (s >> 2) + 4 * h + (i & 3) + 8 * (i >> 2)) * 32 + j];
+        });
+    for (int tap = 0; tap < 9; ++tap)
+        for (int c2 = 0; c2 < 2; ++c2)
+            pack_chunk(out, [&](int h, int i, int j) { return wc[((size_t)tap * 32 + 16 * c2 + 8 * h + i) * 32 + j]; });
+    for (int nt = 0; nt < 4; ++nt)
+        for (int c = 0; c < 2; ++c) pack_chunk(out, [&](int h, int i, int j) { return we[(16 * c + 8 * h + i) * 128 + 32 * nt + j]; });
+    return out;
+}
+
 }  // namespace bf16x3
 }  // namespace ssal

@@ -446,9 +446,229 @@ __global__ __launch_bounds__(256, 3) void k_bottleneck_asym_bf16x3(BnkArgs a, co
     const unsigned img_bytes = (unsigned)(a.H * a.W * C) * 4u;
     expand_store_rows(a, wrs, bf16x3::we_off(10), qa, make_rsrc(ximg, img_bytes), make_rsrc(yimg, img_bytes), boff, lane, j);
 }
+
+// ---- downsample bottleneck 64 -> 128 (Bottleneck2_0; enet_modules.py:868-938) ------------------------------------------------
+// 8 x 16 OUTPUT pixels per workgroup; P = the projected tile with a 1-pixel halo as in the regular kernel.  Projection =
+// the 2x2 / stride-2 convolution as one GEMM over K = 4 taps x 64 channels = 16 chunks; 3x3 convolution as in the regular
+// kernel; expansion as D[co][pixel] with whole-row stores through quad_transpose4.
+// The residual -- max_pool_with_argmax 2x2 / s2 of the block INPUT, zero-padded from 64 to 128 channels -- is EXACT fp32
+// whatever the arithmetic mode (first maximum in (dy, dx) order wins, its window code dy * 2 + dx goes to the upsample block):
+// the pooling indices of a bf16x3 call are the exact path's bit for bit.  It is taken from the projection's OWN activation
+// registers (a second read of the input misses L2: +80 us, measured): the chunks run channel-group-major (the four taps of 16
+// channels in a row), a lane half holds the channels c with (c >> 2) & 1 == h -- exactly the ones the D[co][pixel] expansion
+// hands it -- so the 32 maxima of a lane wait in registers and meet the expansion's output without leaving the lane.
+constexpr int DC = 64;
+
+template <bool POOL>
+__device__ __forceinline__ void project_down(const DownArgs &a, const float *ximg, const rsrc_t &wrs, int q, int ty0, int tx0,
+                                             int Ho, int Wo, unsigned char *P, int lane, int h, float (&pooled)[32],
+                                             const rsrc_t &crs)
+{
+    float4 X[12];  // rolling window of 6 K-chunks
+    const int hr = q / HWP3, hc = q - hr * HWP3;
+    const int pr = ty0 - 1 + hr, pc = tx0 - 1 + hc;
+    const bool valid = (q >= 0) && (pr >= 0) && (pr < Ho) && (pc >= 0) && (pc < Wo);
+    if (__ballot(valid) == 0ull) {  // wave-uniform: the whole M-tile lies outside the image
+        if (q >= 0) {
+#pragma unroll
+            for (int g = 0; g < 12; ++g) *reinterpret_cast<uint4 *>(P + q * PS + 16 * g) = make_uint4(0u, 0u, 0u, 0u);
+        }
+        if (POOL) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) pooled[i] = 0.0f;
+        }
+        return;
+    }
+    const float *xp = valid ? ximg + ((long)(2 * pr) * a.W + 2 * pc) * DC : ximg;
+    const int rowf = a.W * DC;
+    auto load_x = [&](int s) {  // chunk s = 4 cc + t: tap (dy, dx) = (t >> 1, t & 1); channels 16 cc + 4 h + {0..3, 8..11}
+        const float *src = xp + ((s & 2) ? rowf : 0) + ((s & 1) ? DC : 0) + 16 * (s >> 2) + 4 * h;
+        X[2 * (s % 6)] = *reinterpret_cast<const float4 *>(src);
+        X[2 * (s % 6) + 1] = *reinterpret_cast<const float4 *>(src + 8);
+    };
+    float best[8];
+    unsigned cw[8];  // window codes, four channels per word: cw[2 cc + (i >> 2)]
+    auto consume = [&](int s, const Split3 &w, f32x16 acc) {
+        const float4 u = X[2 * (s % 6)], v4 = X[2 * (s % 6) + 1];
+        const float v[8] = {u.x, u.y, u.z, u.w, v4.x, v4.y, v4.z, v4.w};
+        if (POOL) {
+            const int t = s & 3, cc = s >> 2;
+            if (t == 0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) best[i] = v[i];
+                cw[2 * cc] = 0u; cw[2 * cc + 1] = 0u;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const bool gt = v[i] > best[i];  // strict '>' in (dy, dx) order: the first maximum wins
+                    best[i] = gt ? v[i] : best[i];
+                    const unsigned sh = 8u * (i & 3), m = 3u << sh;
+                    cw[2 * cc + (i >> 2)] = gt ? ((cw[2 * cc + (i >> 2)] & ~m) | ((unsigned)t << sh)) : cw[2 * cc + (i >> 2)];
+                }
+            }
+            if (t == 3) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pooled[8 * cc + i] = best[i];
+            }
+        }
+        return mfma6(w, split_pack8(v), acc);  // D[co][pixel]
+    };
+#pragma unroll
+    for (int s = 0; s < 4; ++s) load_x(s);
+    f32x16 acc = {0};
+    Split3 wA = load_w(wrs, bf16x3::DN_WP_OFF, lane), wB;
+#pragma unroll
+    for (int s = 0; s < 16; s += 2) {
+        wB = load_w(wrs, bf16x3::DN_WP_OFF + (s + 1) * bf16x3::CHUNK_UNITS, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        acc = consume(s, wA, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 4 < 16) { load_x(s + 4); load_x(s + 5); }
+        if (s + 2 < 16) wA = load_w(wrs, bf16x3::DN_WP_OFF + (s + 2) * bf16x3::CHUNK_UNITS, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        acc = consume(s + 1, wB, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (POOL) {  // codes of the lane's 32 channels: eight 4-byte stores (channels 16 cc + 4 h + 8 half .. + 3)
+        const unsigned co = valid ? (unsigned)((pr * Wo + pc) * DC + 4 * h) : 0x80000000u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            __builtin_amdgcn_raw_buffer_store_b32(cw[k], crs, co, 16 * (k >> 1) + 8 * (k & 1), 0);
+    }
+    const rsrc_t srs = make_rsrc(a.ps, F * 4), trs = make_rsrc(a.pt, F * 4), ars = make_rsrc(a.pa, F * 4);
+    if (q >= 0) {
+        unsigned char *slot = P + q * PS;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 s4 = bload4(srs, h * 16, g * 32), t4 = bload4(trs, h * 16, g * 32), a4 = bload4(ars, h * 16, g * 32);
+            const float v0 = valid ? prelu1(fmaf(acc[4 * g + 0], s4.x, t4.x), a4.x) : 0.0f;
+            const float v1 = valid ? prelu1(fmaf(acc[4 * g + 1], s4.y, t4.y), a4.y) : 0.0f;
+            const float v2 = valid ? prelu1(fmaf(acc[4 * g + 2], s4.z, t4.z), a4.z) : 0.0f;
+            const float v3 = valid ? prelu1(fmaf(acc[4 * g + 3], s4.w, t4.w), a4.w) : 0.0f;
+            store_split4(slot, 8 * g + 4 * h, v0, v1, v2, v3);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 3) void k_downsample_bf16x3(DownArgs a, const uint4 *wpk)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char P[PSLOTS3 * PS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int Ho = a.H / 2, Wo = a.W / 2;
+    int b = blockIdx.x;
+    const int tx = b % a.tiles_x; b /= a.tiles_x;
+    const int ty = b % a.tiles_y; b /= a.tiles_y;
+    const int n = b;
+    const int ty0 = ty * TH, tx0 = tx * TW;
+    const float *ximg = a.x + (long)n * a.H * a.W * DC;
+    float *yimg = a.y + (long)n * Ho * Wo * C;
+    uint8_t *cimg = a.code + (long)n * Ho * Wo * DC;
+    const rsrc_t wrs = make_rsrc(wpk, bf16x3::DN_UNITS * 16);
+    const rsrc_t crs = make_rsrc(cimg, (unsigned)(Ho * Wo * DC));
+
+    auto q_ring = [&](int u) {
+        const int k = u - 2 * HWP3;
+        return u < HWP3 ? u
+                        : (u < 2 * HWP3 ? (TH + 1) * HWP3 + (u - HWP3)
+                                        : (u < RING3 ? (1 + (k >> 1)) * HWP3 + ((k & 1) ? HWP3 - 1 : 0) : -1));
+    };
+    float pooled[32];  // this lane's pixel (wave * 32 + j): maxima of channels 16 cc + 4 h + (i & 3) + 8 (i >> 2), index 8 cc + i
+    if (wave < 2) project_down<false>(a, ximg, wrs, q_ring(wave * 32 + j), ty0, tx0, Ho, Wo, P, lane, h, pooled, crs);
+    const int tp = wave * 32 + j, tr_ = tp >> 4, tc = tp & 15;
+    project_down<true>(a, ximg, wrs, (tr_ + 1) * HWP3 + tc + 1, ty0, tx0, Ho, Wo, P, lane, h, pooled, crs);
+    __syncthreads();
+
+    // ---- 3x3 conv D[co][pixel], 18 K-chunks ----
+    f32x16 acc = {0};
+    {
+        auto fetch = [&](int q, Split3 &w, Split3 &p) {
+            const int tap = q >> 1, c2 = q & 1, kh = tap / 3, kw = tap - 3 * kh;
+            w = load_w(wrs, bf16x3::DN_WC_OFF + q * bf16x3::CHUNK_UNITS, lane);
+            p = load_p(P + ((tr_ + kh) * HWP3 + (tc + kw)) * PS, c2, h);
+        };
+        Split3 wA, wB, pA, pB;
+        fetch(0, wA, pA);
+#pragma unroll 1
+        for (int q = 0; q < 18; q += 2) {
+            fetch(q + 1, wB, pB);
+            __builtin_amdgcn_sched_barrier(0);
+            acc = mfma6(wA, pA, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 2 < 18) fetch(q + 2, wA, pA);
+            __builtin_amdgcn_sched_barrier(0);
+            acc = mfma6(wB, pB, acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    Split3 qb[2];
+    bn_prelu_to_b(acc, make_rsrc(a.cs, F * 4), make_rsrc(a.ct, F * 4), make_rsrc(a.ca, F * 4), h, qb);
+
+    // ---- expansion 32 -> 128 as D[co][pixel] (lane = pixel, reg 4 g + k = channel 32 nt + 8 g + 4 h + k), + the pooled residual
+    // on channels < 64, PReLU; the four 16-byte pieces of a lane leave as whole 128-byte rows (quad_transpose4) ----
+    constexpr unsigned kOOB = 0x80000000u;
+    const rsrc_t yrs = make_rsrc(yimg, (unsigned)(Ho * Wo * C) * 4u);
+    const rsrc_t esrs = make_rsrc(a.es, C * 4), etrs = make_rsrc(a.et, C * 4), rars = make_rsrc(a.ra, C * 4);
+    unsigned yoq[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int ti = wave * 32 + (j & ~3) + kk;
+        const int pr = ty0 + (ti >> 4), pc = tx0 + (ti & 15);
+        yoq[kk] = (pr < Ho && pc < Wo) ? (unsigned)(((pr * Wo + pc) * C) * 4 + 32 * (j & 3) + 16 * h) : kOOB;
+    }
+    Split3 we0 = load_w(wrs, bf16x3::DN_WE_OFF, lane), we1 = load_w(wrs, bf16x3::DN_WE_OFF + bf16x3::CHUNK_UNITS, lane);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        f32x16 e = {0};
+        e = mfma6(we0, qb[0], e);  // A = kernel (rows = output channels 32 nt + j), B = Q (columns = pixels)
+        e = mfma6(we1, qb[1], e);
+        if (nt < 3) {
+            we0 = load_w(wrs, bf16x3::DN_WE_OFF + (nt * 2 + 2) * bf16x3::CHUNK_UNITS, lane);
+            we1 = load_w(wrs, bf16x3::DN_WE_OFF + (nt * 2 + 3) * bf16x3::CHUNK_UNITS, lane);
+        }
+        float4 ov[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 s4 = bload4(esrs, h * 16, nt * 128 + g * 32), t4 = bload4(etrs, h * 16, nt * 128 + g * 32);
+            const float4 a4 = bload4(rars, h * 16, nt * 128 + g * 32);
+            // channel 32 nt + 8 g + 4 h + k = 16 cc + 4 h + k + 8 (g & 1) with cc = 2 nt + (g >> 1): pooled[8 cc + 4 (g & 1) + k]
+            const int pi = nt < 2 ? 8 * (2 * nt + (g >> 1)) + 4 * (g & 1) : 0;
+            const float r0 = nt < 2 ? pooled[pi + 0] : 0.0f, r1 = nt < 2 ? pooled[pi + 1] : 0.0f;
+            const float r2 = nt < 2 ? pooled[pi + 2] : 0.0f, r3 = nt < 2 ? pooled[pi + 3] : 0.0f;  // channels >= 64: zero padding
+            ov[g].x = prelu1(fmaf(e[4 * g + 0], s4.x, t4.x) + r0, a4.x);
+            ov[g].y = prelu1(fmaf(e[4 * g + 1], s4.y, t4.y) + r1, a4.y);
+            ov[g].z = prelu1(fmaf(e[4 * g + 2], s4.z, t4.z) + r2, a4.z);
+            ov[g].w = prelu1(fmaf(e[4 * g + 3], s4.w, t4.w) + r3, a4.w);
+        }
+        quad_transpose4(ov[0], ov[1], ov[2], ov[3], lane);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov[kk]), yrs, yoq[kk], nt * 128, 0);
+    }
+}
 }  // namespace
 
 bool bottleneck_bf16x3_supported(int Cin, int f) { return Cin == C && f == F; }
+bool downsample_bf16x3_supported(int Cin, int Cout) { return Cin == DC && Cout == C; }
+
+// x [N,H,W,64] -> y [N,H/2,W/2,128], code [N,H/2,W/2,64]; packed = bf16x3::pack_down_layer(...)
+hipError_t launch_downsample_bf16x3(const DownArgs &a0, const void *packed, hipStream_t s)
+{
+    DownArgs a = a0;
+    if (!packed || a.H % 2 || a.W % 2 || a.H < 2 || a.W < 2 || (long)a.H * a.W * DC > (1L << 29)) return hipErrorInvalidValue;
+    const int Ho = a.H / 2, Wo = a.W / 2;
+    a.TH = TH;
+    a.tiles_y = (Ho + TH - 1) / TH;
+    a.tiles_x = (Wo + TW - 1) / TW;
+    const long grid = (long)a.N * a.tiles_y * a.tiles_x;
+    if (grid <= 0 || grid > 0x7fffffffL) return hipErrorInvalidValue;
+    a.trace = nullptr;
+    const double opix = (double)a.N * Ho * Wo;
+    ProfScope prof("k_downsample_bf16x3", 2.0 * opix * (4.0 * DC * F + 9.0 * F * F + F * (double)C),
+                   4.0 * (4.0 * opix * DC + opix * C) + opix * DC, s);
+    hipLaunchKernelGGL(k_downsample_bf16x3, dim3((unsigned)grid), dim3(256), 0, s, a, (const uint4 *)packed);
+    return hipGetLastError();
+}
 
 hipError_t launch_bottleneck_bf16x3(const BnkArgs &a0, const void *packed, hipStream_t s)
 {

@@ -312,8 +312,8 @@ class BottleneckDownsample(Layer):
     def output_shape(self, n, h, w):
         return (n, h // 2, w // 2, self.output_channels)
 
-    def __call__(self, inputs, training, **kwargs):
-        return self._run(inputs, training, want_argmax=True)
+    def __call__(self, inputs, training, arithmetic="f32", **kwargs):
+        return self._run(inputs, training, want_argmax=True, arithmetic=arithmetic)
 
 
 class BottleneckUpsample(Layer):

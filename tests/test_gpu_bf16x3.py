@@ -1,10 +1,10 @@
 """Parity gate of the OPT-IN arithmetic mode ``arithmetic="bf16x3"`` (include/ssal_enet.h SSAL_ARITH_BF16X3;
-csrc/ssal_bottleneck_bf16x3.hip): the sixteen 128-channel regular / dilated / asymmetric bottlenecks evaluate their
+csrc/ssal_bottleneck_bf16x3.hip): the sixteen 128-channel regular / dilated / asymmetric bottlenecks and the downsample block Bottleneck2_0 evaluate their
 convolutions on v_mfma_f32_32x32x16_bf16 with every fp32 operand split into three bf16 terms (six cross products, fp32
 accumulation).  It is a different summation than the oracle's fmaf chains, so it is NOT bit-identical to the default
 mode and has its own gate -- north_star's tolerance: per-pixel softmax / entropy / margin within 1e-4, identical top-k
-example ids; plus, asserted here: pooling indices bit-identical (both pooling layers run in front of these blocks and
-stay exact), per-image float64 scores within 1e-6, logits within 1e-4 of the C oracle.
+example ids; plus, asserted here: pooling indices bit-identical (the first pooling layer runs in front of these blocks; Bottleneck2_0's own max-pool +
+argmax is evaluated in exact fp32 inside its split-operand kernel), per-image float64 scores within 1e-6, logits within 1e-4 of the C oracle.
 
 The default mode ("f32") stays the reference's arithmetic, the bench headline and what every other test checks.
 PARITY STATUS as everywhere: the oracle is this repository's restatement of the reference (TensorFlow is not
@@ -57,8 +57,25 @@ def test_split_operand_blocks_match_the_oracle_within_tolerance(enet_c3k19, name
     assert not np.array_equal(got, exact) or got.size < 256, "the opt-in mode produced the exact kernel's bits: not dispatched?"
 
 
+@pytest.mark.parametrize("n,h,w", [(2, 32, 64), (1, 18, 22), (1, 16, 80), (1, 2, 2), (3, 34, 70), (1, 256, 512)])
+def test_split_operand_downsample_block(enet_c3k19, n, h, w):
+    """Bottleneck2_0 (64 -> 128, 2x2 / s2 projection) under the mode: output within TOL_LAYER of the oracle's exact-fp32 block;
+    the max-pool residual and its window codes are exact fp32 whatever the mode -- the int64 argmax tensor is the oracle's bit
+    for bit; ragged sizes (tiles that cross the border, a single output pixel) and the bench shape"""
+    net, P = enet_c3k19
+    x = np.random.default_rng(h + w).normal(size=(n, h, w, 64)).astype(np.float32)
+    want, want_arg = orc.bottleneck_down(P, "Bottleneck2_0", x)
+    got, arg = net.Bottleneck2_0(dev(x), training=False, arithmetic="bf16x3")
+    report_diff("Bottleneck2_0 bf16x3 argmax (bit-identical)", arg.cpu().numpy(), want_arg)
+    report_diff("Bottleneck2_0 bf16x3 vs oracle", got.cpu().numpy(), want, exact=False, atol=TOL_LAYER)
+    exact, arg0 = net.Bottleneck2_0(dev(x), training=False)
+    report_diff("Bottleneck2_0 default mode still bit-exact", exact.cpu().numpy(), want)
+    assert torch.equal(arg0, arg)
+    assert not torch.equal(got, exact) or got.numel() < 1024, "the opt-in mode produced the exact kernel's bits: not dispatched?"
+
+
 def test_layers_without_a_split_kernel_run_exact(enet_c3k19):
-    """the mode covers Bottleneck2_1 .. 3_8 only: every other layer (both pooling blocks included) runs the exact kernels"""
+    """the mode covers Bottleneck2_0 .. 3_8: every other layer (the first pooling block included) runs the exact kernels"""
     net, P = enet_c3k19
     x16 = np.random.default_rng(3).normal(size=(1, 16, 24, 16)).astype(np.float32)
     want, want_arg = orc.bottleneck_down(P, "Bottleneck1_0", x16)

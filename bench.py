@@ -723,7 +723,7 @@ def main(argv=None):
             # OPT-IN arithmetic, never the headline: the headline line, its dtype and its score_digest stay on the exact kernels
             "c2_bf16x3": secondary_leg(args, ctx, "c2_bf16x3", "enet", 19, 3, "entropy", 0,
                                        "configs[1] workload in the OPT-IN arithmetic mode bf16x3 (ENet.score(arithmetic="
-                                       "'bf16x3'): the sixteen 128-channel bottlenecks + Bottleneck2_0 on split-operand bf16 MFMAs; NOT the "
+                                       "'bf16x3'): the sixteen 128-channel bottlenecks + Bottleneck2_0 / 4_0 on split-operand bf16 MFMAs; NOT the "
                                        "reference's arithmetic, within north_star's 1e-4 / identical top-k: tests/test_gpu_bf16x3.py)",
                                        arithmetic="bf16x3"),
         }

@@ -47,8 +47,8 @@ extern "C" {
 /* arithmetic modes of the *_arith entry points.
  *   SSAL_ARITH_F32     the default and the only mode of every other entry point: exact fp32 (fmaf chains in (kh, kw, ci)
  *                      order on v_mfma_f32_*), bit-identical to the parity oracle.
- *   SSAL_ARITH_BF16X3  OPT-IN: the 128-channel regular / dilated / asymmetric bottlenecks (Bottleneck2_1 .. 3_8) and the
- *                      downsample block Bottleneck2_0 (17 of the 29 launches) evaluate their three convolutions on v_mfma_f32_32x32x16_bf16 with every fp32 operand
+ *   SSAL_ARITH_BF16X3  OPT-IN: the 128-channel regular / dilated / asymmetric bottlenecks (Bottleneck2_1 .. 3_8), the
+ *                      downsample block Bottleneck2_0 and the upsample block Bottleneck4_0 (18 of the 29 launches) evaluate their convolutions on v_mfma_f32_32x32x16_bf16 with every fp32 operand
  *                      split into three bf16 terms and the six leading cross products accumulated in fp32 (what is dropped
  *                      is O(2^-24) relative per product).  Same accuracy class as fp32, a different summation: logits differ
  *                      from the default mode by <= ~1e-5, per-pixel confidences by <= 1e-4 (north_star's tolerance), per-image

@@ -405,6 +405,10 @@ SSAL_API int ssal_enet_commit(ssal_enet *net, void *stream)
             if (sp.kind == K_DOWN && downsample_bf16x3_supported(c, L.cout))  // Bottleneck2_0 of the opt-in mode (129 KB)
                 o.v[15] = ab.push(bf16x3::pack_down_layer(T(net, n + "proj_kernel").data(), T(net, n + "conv_kernel").data(),
                                                           T(net, n + "exp_kernel").data()));
+            if (sp.kind == K_UP && upsample_bf16x3_supported(c, L.cout))  // Bottleneck4_0 of the opt-in mode (117 KB)
+                o.v[15] = ab.push(bf16x3::pack_up_layer(T(net, n + "proj_kernel").data(), T(net, n + "res_kernel").data(),
+                                                        stack_convT(T(net, n + "conv_kernel"), cf, f).data(),
+                                                        T(net, n + "exp_kernel").data()));
             break;
         }
         case K_FINAL:
@@ -612,9 +616,19 @@ hipError_t run_down(const DevLayer &L, const float *x, int n, int h, int w, floa
 // BottleneckUpsample.call (enet_modules.py:1217-1292).  Either window codes (fast path) or the
 // reference's int64 argmax tensor (general scatter path) selects the unpooling.
 hipError_t run_up(const DevLayer &L, const float *x, int n, int h, int w, float *y,
-                  const uint8_t *code, const int64_t *argmax, const LayerTemps &T, hipStream_t s)
+                  const uint8_t *code, const int64_t *argmax, const LayerTemps &T, hipStream_t s, int arith = SSAL_ARITH_F32)
 {
     const int C = L.cin, pf = L.f, cf = L.cf;
+    if (arith == SSAL_ARITH_BF16X3 && L.bf3 && code && up_fused(L, h, w)) {  // opt-in mode; the unpool gather is the exact kernel's
+        UpArgs a;
+        memset(&a, 0, sizeof(a));
+        a.x = x; a.y = y; a.code = code;
+        a.wp = L.proj_w; a.ps = L.proj_scale; a.pt = L.proj_shift; a.pa = L.proj_alpha;
+        a.ws = L.convT_stacked; a.cs = L.conv_scale; a.ct = L.conv_shift; a.ca = L.conv_alpha;
+        a.we = L.exp_w; a.es = L.exp_scale; a.et = L.exp_shift; a.wr = L.res_w; a.ra = L.res_alpha;
+        a.N = n; a.H = h; a.W = w; a.dil = 1;
+        return launch_upsample_bf16x3(a, L.bf3, s);
+    }
     if (code && up_fused(L, h, w))
         return launch_upsample_mfma(x, y, code, n, h, w, C, L.proj_w, L.proj_scale, L.proj_shift,
                                     L.proj_alpha, L.convT_stacked, L.conv_scale, L.conv_shift,
@@ -729,7 +743,7 @@ hipError_t run_layer_idx(const ssal_enet *net, int li, const void *x, bool x_is_
     if (li <= 5) return run_regular(L, (li - 2) % 2 == 0 ? V.s1a : V.s1b, n, h / 4, w / 4, (li - 2) % 2 == 0 ? V.s1b : V.s1a, V.T, s);
     if (li == 6) return run_down(L, V.s1a, n, h / 4, w / 4, V.s2a, V.code2, V.T, s, arith);
     if (li <= 22) return run_regular(L, (li - 7) % 2 == 0 ? V.s2a : V.s2b, n, h / 8, w / 8, (li - 7) % 2 == 0 ? V.s2b : V.s2a, V.T, s, arith);
-    if (li == 23) return run_up(L, V.s2a, n, h / 8, w / 8, V.s1a, V.code2, nullptr, V.T, s);
+    if (li == 23) return run_up(L, V.s2a, n, h / 8, w / 8, V.s1a, V.code2, nullptr, V.T, s, arith);
     if (li <= 25) return run_regular(L, li == 24 ? V.s1a : V.s1b, n, h / 4, w / 4, li == 24 ? V.s1b : V.s1a, V.T, s);
     if (li == 26) return run_up(L, V.s1a, n, h / 4, w / 4, V.a0, V.code1, nullptr, V.T, s);
     return run_regular(L, V.a0, n, h / 2, w / 2, V.a1, V.T, s);
@@ -1069,7 +1083,7 @@ static int run_layer_any(ssal_enet *net, const char *layer, const float *x_dev, 
         HIP_TRY(hipMemcpyAsync(&bad_host, bad, sizeof(int), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         if (bad_host == 0)
-            HIP_TRY(run_up(L, x_dev, n, h, w, y_dev, code, nullptr, T, s));
+            HIP_TRY(run_up(L, x_dev, n, h, w, y_dev, code, nullptr, T, s, arith));
         else
             HIP_TRY(run_up(L, x_dev, n, h, w, y_dev, nullptr, argmax_in_dev, T, s));
         break;

@@ -100,5 +100,26 @@ inline std::vector<float> pack_down_layer(const float *wp, const float *wc, cons
     return out;
 }
 
+// Upsample bottleneck 128 -> 64 (Bottleneck4_0): wp [128][32], wr (residual 1x1) [128][64], ws = the stacked transposed-conv
+// kernel [6 slots][32 ci][32 rows = two output-parity classes x 16 channels] (ssal_api.hip: stack_convT), we [16][64].  Every
+// chunk is an A operand (rows = output channels / stacked rows), the activations are the B operand (columns = pixels).
+constexpr int UP_WP_OFF = 0;                                   // 8 chunks
+constexpr int UP_WR_OFF = 8 * CHUNK_UNITS;                     // chunk 2 c + nt, c = 0..7
+constexpr int UP_WS_OFF = UP_WR_OFF + 16 * CHUNK_UNITS;        // chunk 2 slot + c2
+constexpr int UP_WE_OFF = UP_WS_OFF + 12 * CHUNK_UNITS;        // chunk nt (K = 16: one chunk)
+constexpr int UP_UNITS = UP_WE_OFF + 2 * CHUNK_UNITS;
+inline std::vector<float> pack_up_layer(const float *wp, const float *wr, const float *ws, const float *we)
+{
+    std::vector<float> out;
+    out.reserve((size_t)UP_UNITS * 4);
+    for (int c = 0; c < 8; ++c) pack_chunk(out, [&](int h, int i, int j) { return wp[(16 * c + 8 * h + i) * 32 + j]; });
+    for (int c = 0; c < 8; ++c)
+        for (int nt = 0; nt < 2; ++nt) pack_chunk(out, [&](int h, int i, int j) { return wr[(16 * c + 8 * h + i) * 64 + 32 * nt + j]; });
+    for (int sl = 0; sl < 6; ++sl)
+        for (int c2 = 0; c2 < 2; ++c2) pack_chunk(out, [&](int h, int i, int j) { return ws[((size_t)sl * 32 + 16 * c2 + 8 * h + i) * 32 + j]; });
+    for (int nt = 0; nt < 2; ++nt) pack_chunk(out, [&](int h, int i, int j) { return we[(8 * h + i) * 64 + 32 * nt + j]; });
+    return out;
+}
+
 }  // namespace bf16x3
 }  // namespace ssal

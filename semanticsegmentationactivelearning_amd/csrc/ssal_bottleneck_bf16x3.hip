@@ -646,7 +646,239 @@ __global__ __launch_bounds__(256, 3) void k_downsample_bf16x3(DownArgs a, const 
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov[kk]), yrs, yoq[kk], nt * 128, 0);
     }
 }
+
+// ---- upsample bottleneck 128 -> 64 (Bottleneck4_0; enet_modules.py:1217-1292) ----------------------------------------------
+// 8 x 16 INPUT pixels per workgroup -> 16 x 32 output pixels.  The transposed 3x3 / s2 convolution is evaluated per output
+// parity class of an input pixel from P(i, j), P(i, j-1), P(i-1, j), P(i-1, j-1) (k_upsample_mfma's slots and its stacked
+// kernel: accumulator A = [ee | eo], B = [oe | oo], 16 channels each), so P carries a halo on the top / left only: 9 x 17
+// slots, the 25 ring pixels are one M-tile (wave 0).  The split activations of a centre pixel feed THREE GEMMs per K-chunk --
+// the projection and the two N-tiles of the 1x1 residual convolution (D[co][pixel]: the residual waits in registers in the
+// layout of the expansion's output) -- so the input is read and split once.  unpool_2d is the exact kernel's gather: the
+// residual lands on the output parity its window code names.  Output rows leave as whole 128-byte lines (quad_transpose4).
+constexpr int CU = 64;                        // output channels
+constexpr int HWPU = TW + 1;                  // 17
+constexpr int RINGU = HWPU + TH;              // 25 ring pixels: the top row (17), then the left column of rows 1..8
+constexpr int PSLOTSU = (TH + 1) * HWPU;      // 153
+
+template <bool RES>
+__device__ __forceinline__ void project_up(const UpArgs &a, const float *ximg, const rsrc_t &wrs, int q, int ty0, int tx0,
+                                           unsigned char *P, int lane, int h, f32x16 &res0, f32x16 &res1)
+{
+    float4 X[12];  // rolling window of 6 K-chunks
+    const int hr = q / HWPU, hc = q - hr * HWPU;
+    const int pr = ty0 - 1 + hr, pc = tx0 - 1 + hc;
+    const bool valid = (q >= 0) && (pr >= 0) && (pr < a.H) && (pc >= 0) && (pc < a.W);
+    if (RES) { res0 = (f32x16){0}; res1 = (f32x16){0}; }
+    if (__ballot(valid) == 0ull) {  // wave-uniform: the whole M-tile lies outside the image
+        if (q >= 0) {
+#pragma unroll
+            for (int g = 0; g < 12; ++g) *reinterpret_cast<uint4 *>(P + q * PS + 16 * g) = make_uint4(0u, 0u, 0u, 0u);
+        }
+        return;
+    }
+    const float *xp = valid ? ximg + ((long)pr * a.W + pc) * C : ximg;
+    auto load_x = [&](int c) {
+        X[2 * (c % 6)] = *reinterpret_cast<const float4 *>(xp + 16 * c + 8 * h);
+        X[2 * (c % 6) + 1] = *reinterpret_cast<const float4 *>(xp + 16 * c + 8 * h + 4);
+    };
+#pragma unroll
+    for (int c = 0; c < 4; ++c) load_x(c);
+    f32x16 acc = {0};
+    Split3 wP = load_w(wrs, bf16x3::UP_WP_OFF, lane), wR0, wR1;
+    if (RES) {
+        wR0 = load_w(wrs, bf16x3::UP_WR_OFF, lane);
+        wR1 = load_w(wrs, bf16x3::UP_WR_OFF + bf16x3::CHUNK_UNITS, lane);
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float4 u = X[2 * (c % 6)], w = X[2 * (c % 6) + 1];
+        const float v[8] = {u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w};
+        const Split3 xs = split_pack8(v);
+        __builtin_amdgcn_sched_barrier(0);
+        acc = mfma6(wP, xs, acc);  // D[co][pixel]
+        if (c + 1 < 8) wP = load_w(wrs, bf16x3::UP_WP_OFF + (c + 1) * bf16x3::CHUNK_UNITS, lane);  // single buffers: reloaded right after use
+        if (c + 4 < 8) load_x(c + 4);
+        if (RES) {
+            res0 = mfma6(wR0, xs, res0);
+            if (c + 1 < 8) wR0 = load_w(wrs, bf16x3::UP_WR_OFF + (2 * c + 2) * bf16x3::CHUNK_UNITS, lane);
+            res1 = mfma6(wR1, xs, res1);
+            if (c + 1 < 8) wR1 = load_w(wrs, bf16x3::UP_WR_OFF + (2 * c + 3) * bf16x3::CHUNK_UNITS, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const rsrc_t srs = make_rsrc(a.ps, F * 4), trs = make_rsrc(a.pt, F * 4), ars = make_rsrc(a.pa, F * 4);
+    if (q >= 0) {
+        unsigned char *slot = P + q * PS;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 s4 = bload4(srs, h * 16, g * 32), t4 = bload4(trs, h * 16, g * 32), a4 = bload4(ars, h * 16, g * 32);
+            const float v0 = valid ? prelu1(fmaf(acc[4 * g + 0], s4.x, t4.x), a4.x) : 0.0f;
+            const float v1 = valid ? prelu1(fmaf(acc[4 * g + 1], s4.y, t4.y), a4.y) : 0.0f;
+            const float v2 = valid ? prelu1(fmaf(acc[4 * g + 2], s4.z, t4.z), a4.z) : 0.0f;
+            const float v3 = valid ? prelu1(fmaf(acc[4 * g + 3], s4.w, t4.w), a4.w) : 0.0f;
+            store_split4(slot, 8 * g + 4 * h, v0, v1, v2, v3);
+        }
+    }
+}
+
+// BN + PReLU of a stacked transposed-conv accumulator (reg 4g + k = row 8g + 4h + k; rows 0..15 = the first class, 16..31 =
+// the second, 16 channels each: channel = row & 15) -> the pre-split K = 16 operand of each class (lane (pixel j, h): ci = 8h + i)
+__device__ __forceinline__ void bn16_prelu_to_b(const f32x16 &acc, const rsrc_t &srs, const rsrc_t &trs, const rsrc_t &ars, int h,
+                                                Split3 (&qb)[2])
+{
+    float qv[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 s4 = bload4(srs, h * 16, (g & 1) * 32), t4 = bload4(trs, h * 16, (g & 1) * 32), a4 = bload4(ars, h * 16, (g & 1) * 32);
+        qv[4 * g + 0] = prelu1(fmaf(acc[4 * g + 0], s4.x, t4.x), a4.x);
+        qv[4 * g + 1] = prelu1(fmaf(acc[4 * g + 1], s4.y, t4.y), a4.y);
+        qv[4 * g + 2] = prelu1(fmaf(acc[4 * g + 2], s4.z, t4.z), a4.z);
+        qv[4 * g + 3] = prelu1(fmaf(acc[4 * g + 3], s4.w, t4.w), a4.w);
+    }
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {  // class cc: groups 2cc (channels 4h + k) and 2cc + 1 (channels 8 + 4h + k) exchange halves
+#pragma unroll
+        for (int k = 0; k < 4; ++k) swap32(qv[8 * cc + k], qv[8 * cc + 4 + k]);
+        const float v[8] = {qv[8 * cc + 0], qv[8 * cc + 1], qv[8 * cc + 2], qv[8 * cc + 3],
+                            qv[8 * cc + 4], qv[8 * cc + 5], qv[8 * cc + 6], qv[8 * cc + 7]};
+        qb[cc] = split_pack8(v);
+    }
+}
+
+__global__ __launch_bounds__(256, 3) void k_upsample_bf16x3(UpArgs a, const uint4 *wpk)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char P[PSLOTSU * PS];
+    __shared__ __attribute__((aligned(16))) float BNV[3 * CU];  // es | et | ra
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    int b = blockIdx.x;
+    const int tx = b % a.tiles_x; b /= a.tiles_x;
+    const int ty = b % a.tiles_y; b /= a.tiles_y;
+    const int n = b;
+    const int ty0 = ty * TH, tx0 = tx * TW;
+    const float *ximg = a.x + (long)n * a.H * a.W * C;
+    const uint8_t *cimg = a.code + (long)n * a.H * a.W * CU;
+    float *yimg = a.y + (long)n * 4 * a.H * a.W * CU;
+    const rsrc_t wrs = make_rsrc(wpk, bf16x3::UP_UNITS * 16);
+    if (threadIdx.x < 3 * CU / 4) {
+        const int arr = threadIdx.x / (CU / 4), k4 = threadIdx.x % (CU / 4);
+        const float *src = arr == 0 ? a.es : arr == 1 ? a.et : a.ra;
+        reinterpret_cast<float4 *>(BNV)[threadIdx.x] = reinterpret_cast<const float4 *>(src)[k4];
+    }
+
+    f32x16 res0, res1, d0, d1;
+    if (wave == 0) {  // the ring: slot of ring pixel u = the top row, then the left column
+        const int u = j;
+        const int q = u < HWPU ? u : (u < RINGU ? (u - HWPU + 1) * HWPU : -1);
+        project_up<false>(a, ximg, wrs, q, ty0, tx0, P, lane, h, d0, d1);
+    }
+    const int tp = wave * 32 + j, tr_ = tp >> 4, tc = tp & 15;  // this lane's centre pixel: tile row tr_, column tc
+    project_up<true>(a, ximg, wrs, (tr_ + 1) * HWPU + tc + 1, ty0, tx0, P, lane, h, res0, res1);
+    __syncthreads();
+
+    // window codes of channels 32 nt + 8 g + 4 h .. + 3 (index 4 nt + g) of the lane's input pixel
+    const int iy = ty0 + tr_, ix = tx0 + tc;
+    const bool valid = iy < a.H && ix < a.W;
+    unsigned codes[8];
+    {
+        const rsrc_t crs = make_rsrc(cimg, (unsigned)(a.H * a.W * CU));
+        const unsigned co = valid ? (unsigned)((iy * a.W + ix) * CU + 4 * h) : 0x80000000u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) codes[q] = __builtin_amdgcn_raw_buffer_load_b32(crs, co, 8 * q, 0);
+    }
+    // ---- transposed conv: slots 0..3 -> A = [ee | eo], slots 4, 5 -> B = [oe | oo]; 2 K-chunks per slot ----
+    f32x16 accA = {0}, accB = {0};
+    {
+        auto fetch = [&](int q, Split3 &w, Split3 &p) {  // chunk q = 2 slot + c2
+            const int slot = q >> 1, c2 = q & 1;
+            const int dr = slot < 4 ? 1 - (slot >> 1) : 1, dc = 1 - (slot & 1);
+            w = load_w(wrs, bf16x3::UP_WS_OFF + q * bf16x3::CHUNK_UNITS, lane);
+            p = load_p(P + ((tr_ + dr) * HWPU + (tc + dc)) * PS, c2, h);
+        };
+        Split3 wA, wB, pA, pB;
+        fetch(0, wA, pA);
+#pragma unroll
+        for (int q = 0; q < 12; q += 2) {
+            fetch(q + 1, wB, pB);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q < 8) accA = mfma6(wA, pA, accA); else accB = mfma6(wA, pA, accB);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 2 < 12) fetch(q + 2, wA, pA);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q < 8) accA = mfma6(wB, pB, accA); else accB = mfma6(wB, pB, accB);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const rsrc_t csrs = make_rsrc(a.cs, 16 * 4), ctrs = make_rsrc(a.ct, 16 * 4), cars = make_rsrc(a.ca, 16 * 4);
+    Split3 qcls[4];  // ee, eo, oe, oo
+    {
+        Split3 t2[2];
+        bn16_prelu_to_b(accA, csrs, ctrs, cars, h, t2);
+        qcls[0] = t2[0]; qcls[1] = t2[1];
+        bn16_prelu_to_b(accB, csrs, ctrs, cars, h, t2);
+        qcls[2] = t2[0]; qcls[3] = t2[1];
+    }
+
+    // ---- expansion 16 -> 64 per (class, N-tile) as D[co][pixel] + unpool-gated residual + PReLU, whole-row stores ----
+    const rsrc_t yrs = make_rsrc(yimg, (unsigned)(4 * a.H * a.W * CU) * 4u);
+    unsigned yoq[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int t2 = wave * 32 + (j & ~3) + kk;
+        const int iy2 = ty0 + (t2 >> 4), ix2 = tx0 + (t2 & 15);
+        yoq[kk] = (iy2 < a.H && ix2 < a.W) ? (unsigned)(((2 * iy2) * (2 * a.W) + 2 * ix2) * (CU * 4) + 32 * (j & 3) + 16 * h) : 0x80000000u;
+    }
+    const Split3 we0 = load_w(wrs, bf16x3::UP_WE_OFF, lane), we1 = load_w(wrs, bf16x3::UP_WE_OFF + bf16x3::CHUNK_UNITS, lane);
+    const float *bnl = BNV + 4 * h;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int cls = m >> 1, nt = m & 1;
+        f32x16 e = {0};
+        e = mfma6(nt ? we1 : we0, qcls[cls], e);
+        const unsigned soff = (unsigned)((((cls >> 1) * (2 * a.W) + (cls & 1)) * CU + nt * 32) * 4);
+        float4 ov[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            asm volatile("" ::: "memory");  // keep the LDS reads here (hoisted out of the class loop they would pin registers)
+            const float4 s4 = *reinterpret_cast<const float4 *>(bnl + nt * 32 + 8 * g);
+            const float4 t4 = *reinterpret_cast<const float4 *>(bnl + CU + nt * 32 + 8 * g);
+            const float4 a4 = *reinterpret_cast<const float4 *>(bnl + 2 * CU + nt * 32 + 8 * g);
+            const unsigned cd = codes[4 * nt + g];
+            const f32x16 &rs = nt ? res1 : res0;
+            float4 o;  // unpool_2d as a gather: the residual lands on the output parity its window code names
+            o.x = prelu1(fmaf(e[4 * g + 0], s4.x, t4.x) + (((cd >> 0) & 0xFFu) == (unsigned)cls ? rs[4 * g + 0] : 0.0f), a4.x);
+            o.y = prelu1(fmaf(e[4 * g + 1], s4.y, t4.y) + (((cd >> 8) & 0xFFu) == (unsigned)cls ? rs[4 * g + 1] : 0.0f), a4.y);
+            o.z = prelu1(fmaf(e[4 * g + 2], s4.z, t4.z) + (((cd >> 16) & 0xFFu) == (unsigned)cls ? rs[4 * g + 2] : 0.0f), a4.z);
+            o.w = prelu1(fmaf(e[4 * g + 3], s4.w, t4.w) + (((cd >> 24) & 0xFFu) == (unsigned)cls ? rs[4 * g + 3] : 0.0f), a4.w);
+            ov[g] = o;
+        }
+        quad_transpose4(ov[0], ov[1], ov[2], ov[3], lane);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov[kk]), yrs, yoq[kk], soff, 0);
+    }
+}
 }  // namespace
+
+bool upsample_bf16x3_supported(int Cin, int Cout) { return Cin == C && Cout == CU; }
+
+// x [N,H,W,128] -> y [N,2H,2W,64] with the window codes [N,H,W,64] of the matching downsample; packed = bf16x3::pack_up_layer(...)
+hipError_t launch_upsample_bf16x3(const UpArgs &a0, const void *packed, hipStream_t s)
+{
+    UpArgs a = a0;
+    if (!packed || !a.code || a.H < 1 || a.W < 1 || (long)4 * a.H * a.W * CU > (1L << 29)) return hipErrorInvalidValue;
+    a.TH = TH;
+    a.tiles_y = (a.H + TH - 1) / TH;
+    a.tiles_x = (a.W + TW - 1) / TW;
+    const long grid = (long)a.N * a.tiles_y * a.tiles_x;
+    if (grid <= 0 || grid > 0x7fffffffL) return hipErrorInvalidValue;
+    a.trace = nullptr;
+    const double pix = (double)a.N * a.H * a.W;
+    ProfScope prof("k_upsample_bf16x3", 2.0 * pix * (C * 32.0 + 9.0 * 32 * 16 + 4.0 * 16 * CU + C * (double)CU),
+                   4.0 * (pix * C + 4.0 * pix * CU) + pix * CU, s);
+    hipLaunchKernelGGL(k_upsample_bf16x3, dim3((unsigned)grid), dim3(256), 0, s, a, (const uint4 *)packed);
+    return hipGetLastError();
+}
 
 bool bottleneck_bf16x3_supported(int Cin, int f) { return Cin == C && f == F; }
 bool downsample_bf16x3_supported(int Cin, int Cout) { return Cin == DC && Cout == C; }

@@ -99,6 +99,9 @@ hipError_t launch_bottleneck_bf16x3(const BnkArgs &a, const void *packed, hipStr
 struct DownArgs;
 bool downsample_bf16x3_supported(int Cin, int Cout);
 hipError_t launch_downsample_bf16x3(const DownArgs &a, const void *packed, hipStream_t s);
+struct UpArgs;
+bool upsample_bf16x3_supported(int Cin, int Cout);
+hipError_t launch_upsample_bf16x3(const UpArgs &a, const void *packed, hipStream_t s);
 // MFMA-fused downsample bottleneck 64 -> 128 / 16 -> 64 (writes the 2x2 window codes)
 bool downsample_mfma_supported(int Cin, int Cout);
 hipError_t launch_downsample_mfma(const float *x, float *y, uint8_t *code, int N, int H, int W,

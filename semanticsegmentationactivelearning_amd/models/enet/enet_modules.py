@@ -364,8 +364,8 @@ class BottleneckUpsample(Layer):
     def output_shape(self, n, h, w):
         return (n, 2 * h, 2 * w, self.output_channels)
 
-    def __call__(self, inputs, unpool_argmax, training, **kwargs):
-        return self._run(inputs, training, argmax_in=unpool_argmax)
+    def __call__(self, inputs, unpool_argmax, training, arithmetic="f32", **kwargs):
+        return self._run(inputs, training, argmax_in=unpool_argmax, arithmetic=arithmetic)
 
 
 class Final(Layer):

@@ -1,5 +1,5 @@
 """Parity gate of the OPT-IN arithmetic mode ``arithmetic="bf16x3"`` (include/ssal_enet.h SSAL_ARITH_BF16X3;
-csrc/ssal_bottleneck_bf16x3.hip): the sixteen 128-channel regular / dilated / asymmetric bottlenecks and the downsample block Bottleneck2_0 evaluate their
+csrc/ssal_bottleneck_bf16x3.hip): the sixteen 128-channel regular / dilated / asymmetric bottlenecks, the downsample block Bottleneck2_0 and the upsample block Bottleneck4_0 evaluate their
 convolutions on v_mfma_f32_32x32x16_bf16 with every fp32 operand split into three bf16 terms (six cross products, fp32
 accumulation).  It is a different summation than the oracle's fmaf chains, so it is NOT bit-identical to the default
 mode and has its own gate -- north_star's tolerance: per-pixel softmax / entropy / margin within 1e-4, identical top-k
@@ -74,8 +74,31 @@ def test_split_operand_downsample_block(enet_c3k19, n, h, w):
     assert not torch.equal(got, exact) or got.numel() < 1024, "the opt-in mode produced the exact kernel's bits: not dispatched?"
 
 
+@pytest.mark.parametrize("n,h,w", [(2, 16, 32), (1, 9, 11), (1, 8, 40), (1, 1, 1), (3, 17, 35), (1, 128, 256)])
+def test_split_operand_upsample_block(enet_c3k19, n, h, w):
+    """Bottleneck4_0 (128 -> 64; projection, transposed 3x3 / s2 convolution per output parity, expansion, 1x1 residual
+    convolution + unpool_2d by the pooling indices) under the mode: within TOL_LAYER of the oracle's exact-fp32 block, with real
+    pooling indices (every value in its own 2x2 window, as Bottleneck1_0 / 2_0 produce them); ragged sizes and the bench shape"""
+    net, P = enet_c3k19
+    rng = np.random.default_rng(h * 7 + w)
+    x = rng.normal(size=(n, h, w, 128)).astype(np.float32)
+    # indices of a 2x2 / s2 max-pool of a random [n, 2h, 2w, 64] tensor: flat (y * W + x) * C + c per image, as the reference's
+    big = rng.normal(size=(n, 2 * h, 2 * w, 64)).astype(np.float32)
+    win = big.reshape(n, h, 2, w, 2, 64).transpose(0, 1, 3, 5, 2, 4).reshape(n, h, w, 64, 4)
+    code = win.argmax(-1)  # first maximum in (dy, dx) order
+    yy = 2 * np.arange(h)[None, :, None, None] + code // 2
+    xx = 2 * np.arange(w)[None, None, :, None] + code % 2
+    argmax = ((yy * (2 * w) + xx) * 64 + np.arange(64)[None, None, None, :]).astype(np.int64)
+    want = orc.bottleneck_up(P, "Bottleneck4_0", x, argmax)
+    got = net.Bottleneck4_0(dev(x), dev(argmax), training=False, arithmetic="bf16x3").cpu().numpy()
+    report_diff("Bottleneck4_0 bf16x3 vs oracle", got, want, exact=False, atol=TOL_LAYER)
+    exact = net.Bottleneck4_0(dev(x), dev(argmax), training=False).cpu().numpy()
+    report_diff("Bottleneck4_0 default mode still bit-exact", exact, want)
+    assert not np.array_equal(got, exact) or got.size < 1024, "the opt-in mode produced the exact kernel's bits: not dispatched?"
+
+
 def test_layers_without_a_split_kernel_run_exact(enet_c3k19):
-    """the mode covers Bottleneck2_0 .. 3_8: every other layer (the first pooling block included) runs the exact kernels"""
+    """the mode covers Bottleneck2_0 .. 4_0: every other layer (the first pooling block included) runs the exact kernels"""
     net, P = enet_c3k19
     x16 = np.random.default_rng(3).normal(size=(1, 16, 24, 16)).astype(np.float32)
     want, want_arg = orc.bottleneck_down(P, "Bottleneck1_0", x16)

@@ -570,49 +570,64 @@ struct ClsUpArgs {
     int tiles_x, tiles_y;
 };
 
+// Persistent (round 5): 768 workgroups walk the tiles; the kernel is staged ONCE per workgroup and the source window of the
+// next tile is requested into registers before the current tile's MFMAs (k_conv3x3_c32's scheme), so that a tile no longer
+// starts with an exposed HBM round trip.
 __global__ __launch_bounds__(256) void k_conv1x1_up2_c128(ClsUpArgs a)
 {
     __shared__ __attribute__((aligned(16))) float Ss[CU_SP * CU_LDK];
     __shared__ __attribute__((aligned(16))) float Bs[4 * 32 * IG_LDK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    int b = blockIdx.x;
-    const int tx = b % a.tiles_x; b /= a.tiles_x;
-    const int ty = b % a.tiles_y;
-    const int n = b / a.tiles_y;
-    const int oy0 = ty * HT_H, ox0 = tx * HT_W;  // even
-    const int sy0 = oy0 >> 1, sx0 = ox0 >> 1;
+    const int ntiles = a.N * a.tiles_x * a.tiles_y;
     const int H = 2 * a.Hs, W = 2 * a.Ws;
-
-    // ---- stage source window + kernel: all loads first --------------------------------------------
-    const rsrc_t xrs = make_rsrc(a.x + (long)n * a.Hs * a.Ws * 128, (unsigned)(a.Hs * a.Ws * 512));
-    const rsrc_t wrs = make_rsrc(a.wt, 4u * 32u * 128u);
     constexpr int SQ = CU_SP * 32, SIT = (SQ + 255) / 256;  // float4 quads of the window (32 per pixel)
-    float4 ss[SIT], sb[4];
+    const rsrc_t wrs = make_rsrc(a.wt, 4u * 32u * 128u);
+    float4 ss[SIT];
+    int n = 0, oy0 = 0, ox0 = 0;
+    auto decode = [&](int t, int &n_, int &oy_, int &ox_) {
+        const int tx = t % a.tiles_x; t /= a.tiles_x;
+        const int ty = t % a.tiles_y;
+        n_ = t / a.tiles_y; oy_ = ty * HT_H; ox_ = tx * HT_W;  // even
+    };
+    auto request = [&](int t) {  // the 5 x 9 source pixels of tile t -> registers (out of range past the last tile: zeros nobody reads)
+        int n_, oy_, ox_;
+        decode(t < ntiles ? t : 0, n_, oy_, ox_);
+        const rsrc_t xrs = make_rsrc(a.x + (long)n_ * a.Hs * a.Ws * 128, (unsigned)(a.Hs * a.Ws * 512));
+        const int sy0 = oy_ >> 1, sx0 = ox_ >> 1;
 #pragma unroll
-    for (int it = 0; it < SIT; ++it) {
-        const int e = tid + 256 * it;
-        const int px = min(e >> 5, CU_SP - 1), q = e & 31;
-        const int sy = min(sy0 + px / CU_SW, a.Hs - 1), sx = min(sx0 + px % CU_SW, a.Ws - 1);  // clamped = y1 / x1 rule
-        ss[it] = bload4(xrs, e < SQ ? (unsigned)((sy * a.Ws + sx) * 512 + 16 * q) : IG_OOB, 0);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) sb[t] = bload4(wrs, 16u * (unsigned)tid, (unsigned)t * 4096u);
-    const float bsc = a.scale[r], bsh = a.shift[r];
-#pragma unroll
-    for (int it = 0; it < SIT; ++it) {
-        const int e = tid + 256 * it;
-        if (e < SQ) {  // permuted-k row (igemm_kpos)
-            float *sp = Ss + (e >> 5) * CU_LDK + 8 * ((e & 31) >> 1) + 2 * (e & 1);
-            *reinterpret_cast<float2 *>(sp) = make_float2(ss[it].x, ss[it].z);
-            *reinterpret_cast<float2 *>(sp + 4) = make_float2(ss[it].y, ss[it].w);
+        for (int it = 0; it < SIT; ++it) {
+            const int e = tid + 256 * it;
+            const int px = min(e >> 5, CU_SP - 1), q = e & 31;
+            const int sy = min(sy0 + px / CU_SW, a.Hs - 1), sx = min(sx0 + px % CU_SW, a.Ws - 1);  // clamped = y1 / x1 rule
+            ss[it] = bload4(xrs, (e < SQ && t < ntiles) ? (unsigned)((sy * a.Ws + sx) * 512 + 16 * q) : IG_OOB, 0);
         }
-    }
+    };
+    auto park = [&]() {  // registers -> LDS, permuted-k rows (igemm_kpos)
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-        *reinterpret_cast<float4 *>(Bs + (t * 32 + (tid >> 3)) * IG_LDK + 4 * (tid & 7)) = sb[t];
+        for (int it = 0; it < SIT; ++it) {
+            const int e = tid + 256 * it;
+            if (e < SQ) {
+                float *sp = Ss + (e >> 5) * CU_LDK + 8 * ((e & 31) >> 1) + 2 * (e & 1);
+                *reinterpret_cast<float2 *>(sp) = make_float2(ss[it].x, ss[it].z);
+                *reinterpret_cast<float2 *>(sp + 4) = make_float2(ss[it].y, ss[it].w);
+            }
+        }
+    };
+    int t = blockIdx.x;
+    if (t >= ntiles) return;  // whole workgroup, before any barrier
+    request(t);
+    {
+        float4 sb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sb[q] = bload4(wrs, 16u * (unsigned)tid, (unsigned)q * 4096u);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4 *>(Bs + (q * 32 + (tid >> 3)) * IG_LDK + 4 * (tid & 7)) = sb[q];
+    }
+    const float bsc = a.scale[r], bsh = a.shift[r];
+    park();
     __syncthreads();
-
     // ---- this lane's output pixel and its four source pixels (tf.image.resize_bilinear, legacy mapping) ----
     const int pr = 2 * wave + (r >> 4), pc = r & 15;
     const float ly = (pr & 1) ? 0.5f : 0.0f, lx = (pc & 1) ? 0.5f : 0.0f;
@@ -620,9 +635,6 @@ __global__ __launch_bounds__(256) void k_conv1x1_up2_c128(ClsUpArgs a)
     const float *ptl = Ss + (y0 * CU_SW + x0) * CU_LDK + 4 * h;
     const float *ptr_ = ptl + CU_LDK, *pbl = ptl + CU_SW * CU_LDK, *pbr = pbl + CU_LDK;
     const float *Bb = Bs + r * IG_LDK + 4 * h;
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
     auto lerp4 = [&](const float4 &tl, const float4 &tr, const float4 &bl, const float4 &br) {
         auto l1 = [&](float ctl, float ctr, float cbl, float cbr) {
             const float top = ctl + (ctr - ctl) * lx;
@@ -632,29 +644,39 @@ __global__ __launch_bounds__(256) void k_conv1x1_up2_c128(ClsUpArgs a)
         return make_float4(l1(tl.x, tr.x, bl.x, br.x), l1(tl.y, tr.y, bl.y, br.y), l1(tl.z, tr.z, bl.z, br.z),
                            l1(tl.w, tr.w, bl.w, br.w));
     };
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {  // 8-channel groups in ascending order: chunk g / 4, group g % 4
-        const float4 tl = *reinterpret_cast<const float4 *>(ptl + 8 * g), tr = *reinterpret_cast<const float4 *>(ptr_ + 8 * g);
-        const float4 bl = *reinterpret_cast<const float4 *>(pbl + 8 * g), br = *reinterpret_cast<const float4 *>(pbr + 8 * g);
-        const float4 bf = *reinterpret_cast<const float4 *>(Bb + (g >> 2) * 32 * IG_LDK + 8 * (g & 3));
-        const float4 af = lerp4(tl, tr, bl, br);
-        acc = mfma32(af.x, bf.x, acc);
-        acc = mfma32(af.y, bf.y, acc);
-        acc = mfma32(af.z, bf.z, acc);
-        acc = mfma32(af.w, bf.w, acc);
-    }
-
-    // ---- epilogue ------------------------------------------------------------------------------------
     const bool cok = r < a.Cout;
-    const rsrc_t yrs = make_rsrc(a.y + (long)n * H * W * a.Cout, (unsigned)(H * W * a.Cout * 4));
+    for (; t < ntiles; t += gridDim.x) {
+        decode(t, n, oy0, ox0);
+        request(t + (int)gridDim.x);  // the next tile's window travels under this tile's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int m = (i & 3) + 8 * (i >> 2) + 4 * h;
-        const int oy = oy0 + 2 * wave + (m >> 4), ox = ox0 + (m & 15);
-        float v = fmaf(acc[i], bsc, bsh);
-        if (a.relu) v = v > 0.0f ? v : 0.0f;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs,
-                                              (cok && oy < H && ox < W) ? (unsigned)(((oy * W + ox) * a.Cout + r) * 4) : IG_OOB, 0, 0);
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {  // 8-channel groups in ascending order: chunk g / 4, group g % 4
+            const float4 tl = *reinterpret_cast<const float4 *>(ptl + 8 * g), tr = *reinterpret_cast<const float4 *>(ptr_ + 8 * g);
+            const float4 bl = *reinterpret_cast<const float4 *>(pbl + 8 * g), br = *reinterpret_cast<const float4 *>(pbr + 8 * g);
+            const float4 bf = *reinterpret_cast<const float4 *>(Bb + (g >> 2) * 32 * IG_LDK + 8 * (g & 3));
+            const float4 af = lerp4(tl, tr, bl, br);
+            acc = mfma32(af.x, bf.x, acc);
+            acc = mfma32(af.y, bf.y, acc);
+            acc = mfma32(af.z, bf.z, acc);
+            acc = mfma32(af.w, bf.w, acc);
+        }
+        // ---- epilogue ----
+        const rsrc_t yrs = make_rsrc(a.y + (long)n * H * W * a.Cout, (unsigned)(H * W * a.Cout * 4));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = (i & 3) + 8 * (i >> 2) + 4 * h;
+            const int oy = oy0 + 2 * wave + (m >> 4), ox = ox0 + (m & 15);
+            float v = fmaf(acc[i], bsc, bsh);
+            if (a.relu) v = v > 0.0f ? v : 0.0f;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs,
+                                                  (cok && oy < H && ox < W) ? (unsigned)(((oy * W + ox) * a.Cout + r) * 4) : IG_OOB, 0, 0);
+        }
+        __syncthreads();  // every wave has read its last window fragment
+        park();
+        __syncthreads();
     }
 }
 
@@ -712,7 +734,8 @@ hipError_t launch_igemm(const float *x, int N, int H, int W, int Cin, const floa
         if (grid < (1L << 31)) {
             ProfScope prof("k_conv1x1_up2_c128", 2.0 * (double)a.M * Cin * Cout,
                            4.0 * ((double)N * H * W * Cin + (double)a.M * Cout + (double)Cin * Cout), s);
-            hipLaunchKernelGGL(k_conv1x1_up2_c128, dim3((unsigned)grid), dim3(256), 0, s, q);
+            const long slots = 768 / launch_concurrency();  // persistent: three workgroups per CU over the chains that run side by side
+            hipLaunchKernelGGL(k_conv1x1_up2_c128, dim3((unsigned)(grid < slots ? grid : slots)), dim3(256), 0, s, q);
             return hipGetLastError();
         }
     }

@@ -1097,9 +1097,44 @@ __global__ __launch_bounds__(256) void k_resize_bilinear(const float *__restrict
     }
 }
 
+// the same on channel quads (C % 4 == 0, 16-byte aligned tensors): one 16-byte access per neighbour instead of four 4-byte ones
+__global__ __launch_bounds__(256) void k_resize_bilinear4(const float4 *__restrict__ x, int N, int H, int W, int C4, int OH,
+                                                          int OW, float hs, float ws, float4 *__restrict__ y)
+{
+    const long total = (long)N * OH * OW * C4;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
+        const int c = (int)(o % C4);
+        const long pix = o / C4;
+        const int ox = (int)(pix % OW);
+        const int oy = (int)((pix / OW) % OH);
+        const int n = (int)(pix / ((long)OW * OH));
+        const float fy = (float)oy * hs, fx = (float)ox * ws;
+        const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+        const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float4 *img = x + (long)n * H * W * C4;
+        const float4 tl = img[((long)y0 * W + x0) * C4 + c], tr = img[((long)y0 * W + x1) * C4 + c];
+        const float4 bl = img[((long)y1 * W + x0) * C4 + c], br = img[((long)y1 * W + x1) * C4 + c];
+        auto l1 = [&](float ctl, float ctr, float cbl, float cbr) {
+            const float top = ctl + (ctr - ctl) * lx;
+            const float bot = cbl + (cbr - cbl) * lx;
+            return top + (bot - top) * ly;
+        };
+        y[o] = make_float4(l1(tl.x, tr.x, bl.x, br.x), l1(tl.y, tr.y, bl.y, br.y), l1(tl.z, tr.z, bl.z, br.z), l1(tl.w, tr.w, bl.w, br.w));
+    }
+}
+
 hipError_t launch_resize_bilinear(const float *x, int N, int H, int W, int C, int OH, int OW,
                                   float *y, hipStream_t s)
 {
+    if (C % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+        const long total4 = (long)N * OH * OW * (C / 4);
+        int grid4 = cdiv(total4, 256);
+        if (grid4 > 65536) grid4 = 65536;
+        hipLaunchKernelGGL(k_resize_bilinear4, dim3(grid4), dim3(256), 0, s, (const float4 *)x, N, H, W, C / 4, OH, OW,
+                           (float)H / (float)OH, (float)W / (float)OW, (float4 *)y);
+        return hipGetLastError();
+    }
     const long total = (long)N * OH * OW * C;
     int grid = cdiv(total, 256);
     if (grid > 65536) grid = 65536;

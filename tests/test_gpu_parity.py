@@ -134,16 +134,17 @@ def test_prelu_and_batch_norm_ops():
         xops.batch_norm(dev(x), dev(m), dev(v), dev(g), dev(b), training=True)
 
 
-def test_resize_bilinear_tf113_legacy_mapping():
-    """tf.image.resize_bilinear defaults in TF 1.13: align_corners=False, src = dst * in/out"""
+@pytest.mark.parametrize("c,oh,ow", [(3, 13, 10), (8, 13, 10), (8, 2, 3), (64, 10, 14)])
+def test_resize_bilinear_tf113_legacy_mapping(c, oh, ow):
+    """tf.image.resize_bilinear defaults in TF 1.13: align_corners=False, src = dst * in/out; channel counts that take the scalar
+    kernel (3) and the channel-quad kernel (8, 64), up- and down-scaling"""
     rng = np.random.default_rng(14)
-    x = rng.normal(size=(2, 5, 7, 3)).astype(np.float32)
-    oh, ow = 13, 10
-    y = torch.empty((2, oh, ow, 3), dtype=torch.float32, device="cuda")
+    x = rng.normal(size=(2, 5, 7, c)).astype(np.float32)
+    y = torch.empty((2, oh, ow, c), dtype=torch.float32, device="cuda")
     xd = dev(x)
-    _lib.check(_lib.lib().ssal_resize_bilinear(_lib.dev_ptr(xd), 2, 5, 7, 3, oh, ow, _lib.dev_ptr(y), _lib.stream_ptr()))
+    _lib.check(_lib.lib().ssal_resize_bilinear(_lib.dev_ptr(xd), 2, 5, 7, c, oh, ow, _lib.dev_ptr(y), _lib.stream_ptr()))
     hs, ws = np.float32(5) / np.float32(oh), np.float32(7) / np.float32(ow)
-    want = np.empty((2, oh, ow, 3), np.float32)
+    want = np.empty((2, oh, ow, c), np.float32)
     for oy in range(oh):
         fy = np.float32(oy) * hs
         y0 = int(np.floor(fy)); y1 = min(y0 + 1, 4); ly = np.float32(fy - np.float32(y0))

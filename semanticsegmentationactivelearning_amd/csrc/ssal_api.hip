@@ -1461,6 +1461,7 @@ SSAL_API int ssal_debug_set_knob(const char *name, int value)
     else if (n == "ic_front") k.ic_front = value & 3;
     else if (n == "ic_dual") k.ic_dual = value != 0;
     else if (n == "ig_sb") k.ig_sb = value != 0;
+    else if (n == "ic_groups") k.ic_groups = value;
 #ifdef SSAL_MEASURE
     else if (n == "ablate") k.ablate = value;
     else if (n == "bnk_split") k.bnk_split = value;
@@ -1480,11 +1481,11 @@ SSAL_API int ssal_debug_get_knobs(char *json_out, int64_t cap)
     measure = 1;
     ablate = k.ablate + 100 * k.bnk_split;  // any non-zero value makes `defaults` 0: bench.py refuses to time it as a result
 #endif
-    const int dflt = g_use_mfma && k.bnk_tw == 0 && k.bnk_o4 == 2 && k.bnk_xcd == 1 && k.asym_tw16 == ssal::ASYM_TW16_DEFAULT && k.bnk_qepi == ssal::BNK_QEPI_DEFAULT && k.img_groups == 2 && k.img_span == 4 && k.fuse_ends == 3 && k.img_lag == 0 && k.ig_div == 0 && k.ic_front == ssal::IC_FRONT_DEFAULT && k.ic_dual == ssal::IC_DUAL_DEFAULT && k.ig_sb == ssal::IG_SB_DEFAULT && ablate == 0 && !ssal::prof_enabled()
+    const int dflt = g_use_mfma && k.bnk_tw == 0 && k.bnk_o4 == 2 && k.bnk_xcd == 1 && k.asym_tw16 == ssal::ASYM_TW16_DEFAULT && k.bnk_qepi == ssal::BNK_QEPI_DEFAULT && k.img_groups == 2 && k.img_span == 4 && k.fuse_ends == 3 && k.img_lag == 0 && k.ig_div == 0 && k.ic_front == ssal::IC_FRONT_DEFAULT && k.ic_dual == ssal::IC_DUAL_DEFAULT && k.ig_sb == ssal::IG_SB_DEFAULT && k.ic_groups == ssal::IC_GROUPS_DEFAULT && ablate == 0 && !ssal::prof_enabled()
                      && ssal::g_trace_buf == nullptr;
     snprintf(json_out, (size_t)cap, "{\"kernel_family\": %d, \"bnk_tw\": %d, \"bnk_o4\": %d, \"bnk_xcd\": %d, \"asym_tw16\": %d, \"bnk_qepi\": %d, \"img_groups\": %d, \"img_span\": %d, \"fuse_ends\": %d, "
-             "\"img_lag\": %d, \"ig_div\": %d, \"ic_front\": %d, \"ic_dual\": %d, \"ig_sb\": %d, \"ablate\": %d, \"measure_build\": %d, \"profiling\": %d, \"defaults\": %d}", g_use_mfma ? 1 : 0,
-             k.bnk_tw, k.bnk_o4, k.bnk_xcd, k.asym_tw16, k.bnk_qepi, k.img_groups, k.img_span, k.fuse_ends, k.img_lag, k.ig_div, k.ic_front, k.ic_dual, k.ig_sb, ablate, measure, ssal::prof_enabled() ? 1 : 0, dflt);
+             "\"img_lag\": %d, \"ig_div\": %d, \"ic_front\": %d, \"ic_dual\": %d, \"ig_sb\": %d, \"ic_groups\": %d, \"ablate\": %d, \"measure_build\": %d, \"profiling\": %d, \"defaults\": %d}", g_use_mfma ? 1 : 0,
+             k.bnk_tw, k.bnk_o4, k.bnk_xcd, k.asym_tw16, k.bnk_qepi, k.img_groups, k.img_span, k.fuse_ends, k.img_lag, k.ig_div, k.ic_front, k.ic_dual, k.ig_sb, k.ic_groups, ablate, measure, ssal::prof_enabled() ? 1 : 0, dflt);
     return SSAL_OK;
 }
 

@@ -1458,6 +1458,7 @@ Knobs &knobs()
         q.ic_front = IC_FRONT_DEFAULT;
         q.ic_dual = IC_DUAL_DEFAULT;
         q.ig_sb = IG_SB_DEFAULT;
+        q.ic_groups = IC_GROUPS_DEFAULT;
 #ifdef SSAL_MEASURE  // measurement builds only: the product library reads no environment
         auto env = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
         q.bnk_tw = env("SSAL_BNK_TW", 0);

@@ -391,7 +391,7 @@ int score_any(ssal_icnet *net, const void *x_dev, bool u8, int n, int h, int w, 
     hipStream_t s = (hipStream_t)stream;
     // image-group schedule (same knob and same reasoning as ENet's run_net, ssal_api.hip): the batch runs as G chains of
     // ~n / G images on library-owned side streams, forked from / joined into the caller's stream with events
-    int G = ssal::knobs().img_groups;
+    int G = ssal::knobs().ic_groups;  // ICNet's own chain count (default 1; ENet: img_groups)
     if (G < 2 || G > 8 || n < G || !ssal::mfma_family() || ssal::prof_enabled()) G = 1;
     const int64_t px = (int64_t)h * w, ppm_img = ppm_scratch_floats(1, h / 32, 1024);
     const int blocks = upscore_blocks(h / 4, w / 4);

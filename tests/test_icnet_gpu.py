@@ -379,24 +379,26 @@ def test_repeated_scoring_is_bitwise_stable_at_bench_tile_counts(icnet19):
 
 
 def test_image_group_streams_are_bit_identical(icnet19):
-    """the score path runs as `img_groups` image chains on library-owned side streams (default 2): scores and labels
-    must not depend on the grouping (1, 2, 3 with uneven groups), also for a batch of one"""
+    """ICNet's score path may run as `ic_groups` image chains on library-owned side streams (default 1 since round 5: one chain
+    is faster with the three-workgroup up-sampling kernel; ENet's knob is `img_groups`): scores and labels must not depend on the
+    grouping (1, 2, 3 with uneven groups), also for a batch of one"""
     from semanticsegmentationactivelearning_amd import _lib
     net, _ = icnet19
     x = syn.synth_frames_device(7, 4, 64, 128, 3)
     ref = None
     try:
+        assert _lib.get_knobs()["ic_groups"] == 1
         for g in (1, 2, 3):
-            _lib.set_knob("img_groups", g)
+            _lib.set_knob("ic_groups", g)
             outs = []
             for _ in range(2):
                 s, e = net.score(x, "margin", return_label=True)
                 outs.append((s.cpu().numpy(), e["label"].cpu().numpy(), net.score(x[:1], "margin").cpu().numpy()))
             assert all(np.array_equal(a, b) for a, b in zip(outs[0], outs[1]))
             ref = ref or outs[0]
-            assert all(np.array_equal(a, b) for a, b in zip(outs[0], ref)), "img_groups=%d changes the result" % g
+            assert all(np.array_equal(a, b) for a, b in zip(outs[0], ref)), "ic_groups=%d changes the result" % g
     finally:
-        _lib.set_knob("img_groups", 2)
+        _lib.set_knob("ic_groups", 1)
 
 
 def test_two_host_threads_share_one_handle_and_family_switch(icnet19):
@@ -485,10 +487,17 @@ def test_interleaved_models_batches_and_shapes_match_the_single_stream_unfused_p
     again = run()
     try:
         _lib.set_knob("img_groups", 1)
+        _lib.set_knob("ic_groups", 1)
         _lib.set_knob("fuse_ends", 0)
         want = run()
+        _lib.set_knob("img_groups", 2)
+        _lib.set_knob("ic_groups", 2)  # ICNet on two chains next to ENet's two (not the shipped default any more): same bits
+        _lib.set_knob("fuse_ends", 3)
+        two = run()
+        assert all(np.array_equal(a, b) for a, b in zip(two, want))
     finally:
         _lib.set_knob("img_groups", 2)
+        _lib.set_knob("ic_groups", 1)
         _lib.set_knob("fuse_ends", 3)
     assert len(got) == len(want)
     for i, (a, b, c) in enumerate(zip(got, want, again)):
@@ -508,22 +517,22 @@ def test_fused_branch_fronts_are_bit_identical(icnet19, n, h, w, u8):
         x = (x * 255.0).round().clamp(0, 255).to(torch.uint8)
     shipped = _lib.get_knobs()["ic_front"]
     try:
-        _lib.set_knob("img_groups", 1)
+        _lib.set_knob("ic_groups", 1)
         _lib.set_knob("ic_front", 0)
         s0, e0 = net.score(x, "margin", return_label=True, return_confidence=True)
         want = {k: net.endpoint(k).clone() for k in ("conv2_sub1", "conv1_2_3x3")}
         for front in (1, 2, 3):
             _lib.set_knob("ic_front", front)
             for groups in (1, 2):
-                _lib.set_knob("img_groups", groups)
+                _lib.set_knob("ic_groups", groups)
                 s, e = net.score(x, "margin", return_label=True, return_confidence=True)
                 assert torch.equal(s, s0) and torch.equal(e["label"], e0["label"]) and torch.equal(e["confidence"], e0["confidence"]), \
-                    "ic_front=%d img_groups=%d changes the result" % (front, groups)
+                    "ic_front=%d ic_groups=%d changes the result" % (front, groups)
                 if groups == 1:
                     for k, t in want.items():
                         assert torch.equal(net.endpoint(k), t), "ic_front=%d: %s differs" % (front, k)
     finally:
-        _lib.set_knob("img_groups", 2)
+        _lib.set_knob("ic_groups", 1)
         _lib.set_knob("ic_front", shipped)
 
 
@@ -537,21 +546,21 @@ def test_projection_shortcut_inside_the_increase_launch_is_bit_identical(icnet19
     shipped = _lib.get_knobs()["ic_dual"]
     blocks = ("conv2_1", "conv3_1", "conv4_1", "conv5_1", "conv5_3")
     try:
-        _lib.set_knob("img_groups", 1)
+        _lib.set_knob("ic_groups", 1)
         _lib.set_knob("ic_dual", 0)
         s0, e0 = net.score(x, "margin", return_label=True, return_confidence=True)
         want = {k: net.endpoint(k).clone() for k in blocks}
         _lib.set_knob("ic_dual", 1)
         for groups in (1, 2):
-            _lib.set_knob("img_groups", groups)
+            _lib.set_knob("ic_groups", groups)
             s, e = net.score(x, "margin", return_label=True, return_confidence=True)
             assert torch.equal(s, s0) and torch.equal(e["label"], e0["label"]) and torch.equal(e["confidence"], e0["confidence"]), \
-                "ic_dual=1 img_groups=%d changes the result" % groups
+                "ic_dual=1 ic_groups=%d changes the result" % groups
             if groups == 1:
                 for k, t in want.items():
                     assert torch.equal(net.endpoint(k), t), "ic_dual=1: %s differs" % k
     finally:
-        _lib.set_knob("img_groups", 2)
+        _lib.set_knob("ic_groups", 1)
         _lib.set_knob("ic_dual", shipped)
 
 

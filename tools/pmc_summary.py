@@ -20,6 +20,8 @@ def short(name):
         return "k_front2<s%s>" % n.rstrip(">").split(",")[-1].strip()
     if n.startswith("k_bottleneck_bf16x3") or n.startswith("k_bottleneck_asym_bf16x3"):
         return n.split("<")[0]
+    if n.startswith("k_bottleneck_mfma<"):  # k_bottleneck_mfma<32, 2> (tile width, epilogue form) -> the launcher's profile name k_bottleneck_mfma<32>
+        return "k_bottleneck_mfma<%s>" % n[n.index("<") + 1:n.rindex(">")].split(",")[0].strip()
     if n.startswith("k_bottleneck16") or n.startswith("k_bottleneck_mfma"):
         return n.replace(" ", "")
     if n.startswith("k_final_score"):  # k_final_score<19, false, true> = Bottleneck5_1 evaluated inside (bench: "k_final_score<fused 5_1>")

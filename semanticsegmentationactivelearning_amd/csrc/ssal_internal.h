@@ -127,7 +127,7 @@ hipError_t launch_upsample_mfma(const float *x, float *y, const uint8_t *code, i
 // ssal_debug_set_knob for A/B runs and for the tests that compare the variants bit for bit: every setting of the
 // product build produces identical results.  Work-skipping "ablate" and the SSAL_* environment reads exist only in
 // -DSSAL_MEASURE builds).
-constexpr int IC_FRONT_DEFAULT = 1, IC_DUAL_DEFAULT = 1, ASYM_TW16_DEFAULT = 1, IG_SB_DEFAULT = 1, IC_GROUPS_DEFAULT = 1, BNK_QEPI_DEFAULT = 2;
+constexpr int IC_FRONT_DEFAULT = 3, IC_DUAL_DEFAULT = 1, ASYM_TW16_DEFAULT = 1, IG_SB_DEFAULT = 1, IC_GROUPS_DEFAULT = 1, BNK_QEPI_DEFAULT = 2;
 struct Knobs {
     int bnk_tw;      // 16 = force 8x16 tiles in the 128-channel bottleneck kernels
     int bnk_o4;      // k_bottleneck_o4 (8x16 tiles, four workgroups per CU): 2 (default) = where the phase sub-image is <= 16 wide, 1 = everywhere, 0 = never

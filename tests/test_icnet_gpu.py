@@ -576,18 +576,20 @@ def test_endpoint_after_score_raises_for_layers_inside_fused_launches(icnet19):
     swallowed = [nm for nm in net.endpoint_names()
                  if _lib.lib().ssal_icnet_endpoint_valid_after_score(net._handle, nm.encode(), 64, 64) == 0]
     assert "conv1_sub1" in swallowed and "conv2_1_1x1_proj" in swallowed and "conv2_2_3x3" in swallowed
+    assert "conv1_1_3x3_s2" in swallowed  # both branch fronts run as one launch each since round 5 (ic_front = 3)
     assert "conv6_cls" not in swallowed and "conv2_2" not in swallowed and "conv2_sub1" not in swallowed
     for nm in swallowed:
         with pytest.raises(RuntimeError, match="not written by score"):
             net.endpoint(nm)
     assert net.endpoint("conv6_cls").shape == (1, 16, 16, 19)
+    shipped_front = _lib.get_knobs()["ic_front"]
     try:  # with the fused front and the dual launches off, those buffers ARE written by a score call
         _lib.set_knob("ic_front", 0)
         _lib.set_knob("ic_dual", 0)
         net.score(x, measure="margin")
         assert net.endpoint("conv1_sub1").shape == (1, 32, 32, 32) and net.endpoint("conv2_1_1x1_proj").shape[-1] == 128
     finally:
-        _lib.set_knob("ic_front", 1)
+        _lib.set_knob("ic_front", shipped_front)
         _lib.set_knob("ic_dual", 1)
     assert _lib.lib().ssal_icnet_endpoint_valid_after_score(net._handle, b"no_such_layer", 64, 64) == -1
     net(x, training=False)

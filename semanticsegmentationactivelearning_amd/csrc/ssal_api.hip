@@ -1460,7 +1460,7 @@ SSAL_API int ssal_debug_set_knob(const char *name, int value)
     else if (n == "ig_div") k.ig_div = value > 0 ? value : 0;
     else if (n == "ic_front") k.ic_front = value & 3;
     else if (n == "ic_dual") k.ic_dual = value != 0;
-    else if (n == "ig_sb") k.ig_sb = value != 0;
+    else if (n == "ig_sb") k.ig_sb = value;
     else if (n == "ic_groups") k.ic_groups = value;
 #ifdef SSAL_MEASURE
     else if (n == "ablate") k.ablate = value;

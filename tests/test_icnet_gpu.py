@@ -564,6 +564,29 @@ def test_projection_shortcut_inside_the_increase_launch_is_bit_identical(icnet19
         _lib.set_knob("ic_dual", shipped)
 
 
+@pytest.mark.parametrize("n,h,w", [(2, 64, 96), (1, 160, 224)])
+def test_single_lds_buffer_igemm_is_bit_identical(icnet19, n, h, w):
+    """knob ig_sb: k_igemm with ONE LDS buffer at three workgroups per CU (2, shipped: the up-sampling form and the plain form
+    at NT = 2; 1: the up-sampling form only; 0: double-buffered everywhere): block outputs, logits and scores are the same bits"""
+    net, _ = icnet19
+    x = syn.synth_frames_device(33, n, h, w, 3)
+    shipped = _lib.get_knobs()["ig_sb"]
+    assert shipped == 2
+    try:
+        _lib.set_knob("ig_sb", 0)
+        want_logits = net(x, training=False).clone()
+        want = {k: net.endpoint(k).clone() for k in ("sub24_sum", "sub12_sum", "conv5_4_k1", "conv3_1")}
+        s0 = net.score(x, "margin")
+        for sb in (1, 2):
+            _lib.set_knob("ig_sb", sb)
+            assert torch.equal(net(x, training=False), want_logits), "ig_sb=%d changes the logits" % sb
+            for k, t in want.items():
+                assert torch.equal(net.endpoint(k), t), "ig_sb=%d: %s differs" % (sb, k)
+            assert torch.equal(net.score(x, "margin"), s0)
+    finally:
+        _lib.set_knob("ig_sb", shipped)
+
+
 def test_endpoint_after_score_raises_for_layers_inside_fused_launches(icnet19):
     """score() runs fused launches that never write some ICNET_SPEC layer outputs; endpoint() of such a name
     after a score() must raise instead of returning a stale slice of the torch.empty workspace.  After a forward every

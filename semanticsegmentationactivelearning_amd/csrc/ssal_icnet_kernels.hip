@@ -59,7 +59,7 @@ constexpr unsigned IG_OOB = 0xFFFFFFFFu;  // a byte offset no tensor reaches: ra
 // chunk): 36.9 KB at NT = 4 and <= 168 VGPRs -- three workgroups per CU instead of two.  Measured (profiles/
 // r05_ab_igemm_single_lds_buffer.txt): the up-sampling form, whose load + interpolation phases are the longest, gains 3 %
 // (conv_sub2 / conv_sub4); the plain form loses 7 % at NT = 4 and gains 1 % at NT = 2; four workgroups per CU (128 VGPRs:
-// 20-37 spilled) lose 4 %.  Used for UP2 = 2 and, since ICNet runs on one chain, for the plain form at NT = 2 (knob ig_sb).
+// 20-37 spilled) lose 4 %.  Used for UP2 = 2 and, since ICNet runs on one chain, for the plain form at NT = 1 / 2 (knob ig_sb).
 template <int NT, int UP2, bool DUAL = false, bool SB = false>
 __global__ __launch_bounds__(256, SB ? 3 : 1) void k_igemm(IgemmArgs a0)
 {
@@ -782,10 +782,11 @@ hipError_t launch_igemm(const float *x, int N, int H, int W, int Cin, const floa
     // the four-adjacent-pixels loader of the up-sampling form (k_igemm<.., 2>): see the kernel's header
     const bool adj = up2 && stride == 1 && a.Wo % 4 == 0 && dil % 2 == 0 && a.pad_l % 2 == 0;
     const bool sb = adj && NT >= 2 && knobs().ig_sb != 0;  // one LDS buffer, three workgroups per CU (see the kernel's header)
-    const bool sb2 = !up2 && NT == 2 && knobs().ig_sb == 2;  // the plain form at NT = 2 as well (27.6 KB): +0.35 % on the one-chain pass
+    const bool sb2 = !up2 && NT == 2 && knobs().ig_sb >= 2;  // the plain form at NT = 2 (27.6 KB: +0.35 % on the one-chain pass) and, from ig_sb = 3, at NT = 1 (23 KB: +0.8 %); NT = 4: -0.6 %, not used
 #define SSAL_IG(N_)                                                                         \
     if (sb) hipLaunchKernelGGL((k_igemm<(N_ < 2 ? 2 : N_), 2, false, true>), dim3(grid), dim3(256), 0, s, a);   \
     else if (sb2) hipLaunchKernelGGL((k_igemm<2, 0, false, true>), dim3(grid), dim3(256), 0, s, a);   \
+    else if (!up2 && NT == 1 && knobs().ig_sb >= 3) hipLaunchKernelGGL((k_igemm<1, 0, false, true>), dim3(grid), dim3(256), 0, s, a);   \
     else if (adj) hipLaunchKernelGGL((k_igemm<N_, 2>), dim3(grid), dim3(256), 0, s, a);    \
     else if (up2) hipLaunchKernelGGL((k_igemm<N_, 1>), dim3(grid), dim3(256), 0, s, a);    \
     else hipLaunchKernelGGL((k_igemm<N_, 0>), dim3(grid), dim3(256), 0, s, a)

@@ -127,7 +127,7 @@ hipError_t launch_upsample_mfma(const float *x, float *y, const uint8_t *code, i
 // ssal_debug_set_knob for A/B runs and for the tests that compare the variants bit for bit: every setting of the
 // product build produces identical results.  Work-skipping "ablate" and the SSAL_* environment reads exist only in
 // -DSSAL_MEASURE builds).
-constexpr int IC_FRONT_DEFAULT = 3, IC_DUAL_DEFAULT = 1, ASYM_TW16_DEFAULT = 1, IG_SB_DEFAULT = 2, IC_GROUPS_DEFAULT = 1, BNK_QEPI_DEFAULT = 2;
+constexpr int IC_FRONT_DEFAULT = 3, IC_DUAL_DEFAULT = 1, ASYM_TW16_DEFAULT = 1, IG_SB_DEFAULT = 3, IC_GROUPS_DEFAULT = 1, BNK_QEPI_DEFAULT = 2;
 struct Knobs {
     int bnk_tw;      // 16 = force 8x16 tiles in the 128-channel bottleneck kernels
     int bnk_o4;      // k_bottleneck_o4 (8x16 tiles, four workgroups per CU): 2 (default) = where the phase sub-image is <= 16 wide, 1 = everywhere, 0 = never
@@ -136,7 +136,7 @@ struct Knobs {
     int asym_tw16;   // asymmetric 128-channel block: 1 = k_bottleneck_mfma_asym16x (8x16 tiles, 3 workgroups per CU, (5,1) result written over the projected rows), 0 = the 8x32 / two-halves kernel
     int fuse_ends;   // bit 0: Initial + Bottleneck1_0 in one launch; bit 1: Bottleneck5_1 inside Final + score (ranking pass); default 3
     int ic_groups;   // ICNet score path: image-group chains (1, default: with the three-workgroup up-sampling kernel one chain is 2.5 % faster than two; ENet keeps img_groups = 2)
-    int ig_sb;       // k_igemm with ONE LDS buffer at three workgroups per CU: 0 = never, 1 = the up-sampling form (UP2 = 2), 2 (default) = that and the plain form at NT = 2
+    int ig_sb;       // k_igemm with ONE LDS buffer at three workgroups per CU: 0 = never, 1 = the up-sampling form (UP2 = 2), 2 = that and the plain form at NT = 2, 3 (default) = also at NT = 1
     int ic_dual;     // ICNet score path: 1 = a block's projection shortcut is evaluated inside its increase launch (k_igemm<.., DUAL>)
     int ic_front;    // ICNet score path: bit 0 = conv1_sub1 + conv2_sub1 in one launch (k_front2<s2>), bit 1 = conv1_1_3x3_s2 + conv1_2_3x3 (k_front2<s1>)
     int ig_div;      // ICNet: the ">= 512 workgroups per launch" rules of k_igemm / k_conv3x3_c32 use 512 / ig_div; 0 (default) = the number of image-group chains of the call

@@ -566,18 +566,19 @@ def test_projection_shortcut_inside_the_increase_launch_is_bit_identical(icnet19
 
 @pytest.mark.parametrize("n,h,w", [(2, 64, 96), (1, 160, 224)])
 def test_single_lds_buffer_igemm_is_bit_identical(icnet19, n, h, w):
-    """knob ig_sb: k_igemm with ONE LDS buffer at three workgroups per CU (2, shipped: the up-sampling form and the plain form
-    at NT = 2; 1: the up-sampling form only; 0: double-buffered everywhere): block outputs, logits and scores are the same bits"""
+    """knob ig_sb: k_igemm with ONE LDS buffer at three workgroups per CU (3, shipped: the up-sampling form and the plain form
+    at NT = 1 / 2; 2: without NT = 1; 1: the up-sampling form only; 0: double-buffered everywhere): block outputs, logits and
+    scores are the same bits"""
     net, _ = icnet19
     x = syn.synth_frames_device(33, n, h, w, 3)
     shipped = _lib.get_knobs()["ig_sb"]
-    assert shipped == 2
+    assert shipped == 3
     try:
         _lib.set_knob("ig_sb", 0)
         want_logits = net(x, training=False).clone()
         want = {k: net.endpoint(k).clone() for k in ("sub24_sum", "sub12_sum", "conv5_4_k1", "conv3_1")}
         s0 = net.score(x, "margin")
-        for sb in (1, 2):
+        for sb in (1, 2, 3):
             _lib.set_knob("ig_sb", sb)
             assert torch.equal(net(x, training=False), want_logits), "ig_sb=%d changes the logits" % sb
             for k, t in want.items():
